@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): 1 s-strain segments/s through the whisper-tiny
+encoder forward at batch 256 x (80 x 3000) log-mel, bf16 MFMA, on N MI355X GPUs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch: [256, 80, 3000] fp32 log-mel
+(already resident in HBM, produced by the HIP front end from seeded 1 s strain) ->
+conv stem -> 4 pre-LN layers (LN, QKV, MHSA over all 1500 tokens, out-proj, FFN) ->
+final LayerNorm -> last_hidden_state [256, 1500, 384] fp32 AND the pooled last token.
+Data-parallel: every rank runs its own batch (weak scaling), no collective on the
+inference path.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     : the dominant kernel (by time) against the gfx950 bf16 dense MFMA peak,
+                 its duration measured live with HIP events on the launch stream
+  cpu_baseline : the numpy oracle (a port, not the reference) timed on this box's host
+                 cores on a bounded sample of the same workload
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
+HBM_PEAK_GBS = 8000.0
+T_TOK, T_IN, DH = 1500, 3000, 64
+
+
+def flops_per_segment(d, L, H, ffn, n_mels=80):
+    """Algorithmic FLOPs (2 x MAC) of one encoder forward, BASELINE.md section 2."""
+    conv1 = 2 * T_IN * (3 * n_mels) * d
+    conv2 = 2 * T_TOK * (3 * d) * d
+    proj = 2 * T_TOK * d * d * 4
+    attn = 2 * 2 * T_TOK * T_TOK * DH * H
+    ffn_f = 2 * 2 * T_TOK * d * ffn
+    return {"conv1": conv1, "conv2": conv2, "proj": proj, "attn": attn, "ffn": ffn_f,
+            "total": conv1 + conv2 + L * (proj + attn + ffn_f)}
+
+
+def time_kernel(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters   # ms per launch
+
+
+def kernel_breakdown(enc_name, B, dev):
+    """Per-kernel durations at the bench shapes through the kernel-level C-ABI entry
+    points (HIP events on the launch stream)."""
+    from gw_whisper_amd import ops, synth
+    d, L, H, ffn = synth.ENCODER_SIZES[enc_name]
+    M = B * T_TOK
+    g = torch.Generator(device="cpu").manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x32 = rnd(M, d).to(dev)
+    h = x32.bfloat16()
+    wqkv = (rnd(3 * d, d) / d ** 0.5).to(dev).bfloat16()
+    wo = (rnd(d, d) / d ** 0.5).to(dev).bfloat16()
+    w1 = (rnd(ffn, d) / d ** 0.5).to(dev).bfloat16()
+    w2 = (rnd(d, ffn) / ffn ** 0.5).to(dev).bfloat16()
+    bqkv, bo, b1 = rnd(3 * d).to(dev), rnd(d).to(dev), rnd(ffn).to(dev)
+    lnw, lnb = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+    qkv = (rnd(B, T_TOK, 3 * d) * 0.5).to(dev).bfloat16()
+    f1 = rnd(M, ffn).to(dev).bfloat16()
+    fl = flops_per_segment(d, L, H, ffn)
+    rows = []
+
+    def add(name, fn, flops, bytes_):
+        ms = time_kernel(fn)
+        rows.append({"kernel": name, "ms": ms, "launches_per_fwd": L, "tflops": flops / ms / 1e9 if flops else None,
+                     "gbs": bytes_ / ms / 1e6})
+
+    add("layernorm", lambda: ops.layernorm(x32, lnw, lnb, out_bf16=True), 0, M * d * 6)
+    add("gemm_qkv", lambda: ops.gemm(h, wqkv, bqkv, 0), B * 2 * T_TOK * d * 3 * d, M * d * 2 + M * 3 * d * 2)
+    add("attention", lambda: ops.attention(qkv, H), B * fl["attn"], M * 4 * d * 2)
+    add("gemm_out_resid", lambda: ops.gemm(h, wo, bo, 2, resid=x32), B * 2 * T_TOK * d * d, M * d * 10)
+    add("gemm_fc1_gelu", lambda: ops.gemm(h, w1, b1, 1), B * 2 * T_TOK * d * ffn, M * (d + ffn) * 2)
+    add("gemm_fc2_resid", lambda: ops.gemm(f1, w2, bo, 2, resid=x32), B * 2 * T_TOK * d * ffn, M * (ffn * 2 + d * 8))
+    rows[0]["launches_per_fwd"] = 2 * L + 1
+    return rows
+
+
+def cpu_baseline(enc_name, n_seg=6):
+    """The numpy oracle (a CPU port of the HF arithmetic, not the reference itself) on a
+    bounded sample: n_seg segments of the same workload, all host cores via BLAS."""
+    from gw_whisper_amd import synth
+    from oracle import encoder as oenc
+    from oracle import logmel as olm
+    sd = synth.named_encoder_state_dict(enc_name, seed=0)
+    cfg = oenc.EncCfg.named(enc_name)
+    mel = olm.log_mel(synth.strain_segments(n_seg, seed=0))
+    oenc.encoder_forward(sd, mel[:1], cfg)                       # warm BLAS threads
+    t0 = time.perf_counter()
+    oenc.encoder_forward(sd, mel, cfg)
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": n_seg / dt, "unit": "segments/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n_seg} segments x [80,3000] log-mel, whisper-{enc_name} encoder fwd, numpy fp32 oracle, "
+                      f"{dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--encoder", default="tiny")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gw_whisper_amd import ops, synth
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+
+    d, L, H, ffn = synth.ENCODER_SIZES[args.encoder]
+    B = args.batch
+    sd = synth.named_encoder_state_dict(args.encoder, seed=0)
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig.named(args.encoder), precision=args.precision).to(dev)
+    # synthetic whitened-like 1 s strain -> HIP log-mel front end; features stay resident in HBM
+    wave = torch.from_numpy(synth.strain_segments(B, seed=1000 + rank)).to(dev)
+    mel = ops.logmel(wave)
+    fe_ms = time_kernel(lambda: ops.logmel(wave), iters=5, warm=1)
+
+    def step():
+        return enc.forward_raw(mel, want_hidden=True, want_last=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        dt = time.perf_counter() - t0
+    assert torch.isfinite(out[1]).all()
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    if rank == 0:
+        fl = flops_per_segment(d, L, H, ffn)
+        fwd_tflops = B * fl["total"] / (ms_per_step * 1e-3) / 1e12
+        line = {
+            "metric": "1s-strain segments/sec (encoder fwd)",
+            "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"whisper-{args.encoder} encoder fwd, batch {B} log-mel (80x3000) per GPU, "
+                                   f"1500 tokens, random-init weights (configs[1])",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "encoder": args.encoder},
+            "forward": {"algorithmic_gflop_per_segment": fl["total"] / 1e9, "achieved_tflops_per_gpu": fwd_tflops,
+                        "frac_of_bf16_mfma_peak": fwd_tflops / MFMA_BF16_PEAK_TFLOPS},
+            "frontend": {"kernel": "logmel (k_logmel_frames + k_logmel_finalize)", "ms_per_batch": fe_ms,
+                         "segments_per_s": B / fe_ms * 1e3,
+                         "algorithmic_gbs": B * (64000 + 960000) / fe_ms / 1e6,
+                         "frac_of_hbm_peak": B * (64000 + 960000) / fe_ms / 1e6 / HBM_PEAK_GBS},
+            "dora_step_ms": None,
+        }
+        if not args.no_breakdown and args.precision == "bf16":
+            rows = kernel_breakdown(args.encoder, B, dev)
+            line["kernels"] = rows
+            dom = max(rows, key=lambda r: r["ms"] * r["launches_per_fwd"])
+            if dom["tflops"]:
+                line["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
+                                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": dom["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                                    "ms_per_launch": dom["ms"]}
+            else:
+                line["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["gbs"],
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS,
+                                    "traffic": None, "ms_per_launch": dom["ms"]}
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.encoder)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+// Shared device/host helpers for libgww (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gww.h"
+
+namespace gww {
+
+// ---- error plumbing -------------------------------------------------------
+extern thread_local char g_err[512];
+int fail(int code, const char* fmt, ...);
+
+#define GWW_HIP(expr)                                                                 \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess)                                                             \
+      return ::gww::fail(GWW_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                         __FILE__, __LINE__);                                         \
+  } while (0)
+
+#define GWW_LAUNCH_CHECK() GWW_HIP(hipGetLastError())
+
+#define GWW_REQUIRE(cond, ...)                       \
+  do {                                               \
+    if (!(cond)) return ::gww::fail(GWW_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+
+// ---- vector types ---------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int kWave = 64;
+
+// fp32 -> bf16 bits, round to nearest even.  A plain cast lowers to
+// v_cvt_pk_bf16_f32 on gfx950 and keeps NaNs NaN.
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf2f(unsigned short u) {
+  return __builtin_bit_cast(float, ((unsigned int)u) << 16);
+}
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
+  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact (erf) GELU, nn.functional.gelu default
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+// ---- kernels launched from more than one translation unit ------------------
+// (definitions in the .hip files; every launcher returns a gww status code)
+int launch_layernorm(const float* x, const float* w, const float* b, void* y, int out_bf16,
+                     long M, int d, hipStream_t s);
+int launch_layernorm_rows(const float* x, long row_stride, const float* w, const float* b, float* y,
+                          long M, int d, hipStream_t s);
+int launch_cast_f32_bf16(const float* x, void* y, long n, hipStream_t s);
+int launch_pack_weight(const float* w, void* out, int out_bf16, int N, int C, int taps, int Kpad,
+                       float scale, hipStream_t s);
+int launch_scale_copy(const float* in, float* out, int n, float scale, hipStream_t s);
+int launch_gemm_bf16(const void* A, long lda, const void* W, const float* bias, const float* resid,
+                     const float* pos, void* C, long M, int N, int K, int epi, int rows_per_batch,
+                     hipStream_t s);
+int launch_gemm_f32(const float* A, long lda, const float* W, const float* bias, const float* resid,
+                    const float* pos, float* C, long M, int N, int K, int epi, int rows_per_batch,
+                    hipStream_t s);
+int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipStream_t s);
+int launch_attention_f32(const float* qkv, float* ctx, int B, int T, int H, hipStream_t s);
+int launch_conv1_bf16(const float* mel, const void* w_packed, const float* bias, void* out,
+                      int B, int T, int n_mels, int d, hipStream_t s);
+int launch_conv1_f32(const float* mel, const float* w_packed, const float* bias, float* out,
+                     int B, int T, int n_mels, int d, hipStream_t s);
+
+// GEMM epilogues
+enum : int {
+  EPI_BIAS = 0,        // C = acc + bias                    (bf16 / f32 store)
+  EPI_GELU = 1,        // C = gelu(acc + bias)
+  EPI_RESID = 2,       // C(f32) = resid + acc + bias       (may alias resid)
+  EPI_CONV2 = 3,       // conv2: gelu(acc+bias) + pos[t], rows remapped (see gemm_bf16.hip)
+};
+
+}  // namespace gww

@@ -1,0 +1,225 @@
+// Row-wise / elementwise kernels: LayerNorm, casts, weight packing, DoRA merge.
+// All HBM-bound; one wave per row with float2 lanes (d is a multiple of 128 for
+// every Whisper size: 384 / 512 / 768 / 1024 / 1280).
+#include "common.h"
+
+namespace gww {
+
+thread_local char g_err[512] = {0};
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ---------------------------------------------------------------- LayerNorm
+// HF:modeling_whisper.py:392,402,642 (nn.LayerNorm, eps 1e-5, affine).
+// NV = d / 128 float2 per lane.  Two-pass (mean, then centred variance) in registers.
+template <int NV, bool OUT_BF16>
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, long row_stride,
+                                                   const float* __restrict__ w,
+                                                   const float* __restrict__ b, void* __restrict__ y,
+                                                   long M) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  constexpr int d = NV * 128;
+  const float2* xr = reinterpret_cast<const float2*>(x + row * row_stride);
+  float2 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j] = xr[lane + 64 * j];
+    s += v[j].x + v[j].y;
+  }
+  const float mean = wave_sum(s) * (1.0f / d);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j].x -= mean;
+    v[j].y -= mean;
+    q += v[j].x * v[j].x + v[j].y * v[j].y;
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / d) + 1e-5f);
+  const float2* w2 = reinterpret_cast<const float2*>(w);
+  const float2* b2 = reinterpret_cast<const float2*>(b);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const float2 ww = w2[lane + 64 * j], bb = b2[lane + 64 * j];
+    const float o0 = v[j].x * rstd * ww.x + bb.x;
+    const float o1 = v[j].y * rstd * ww.y + bb.y;
+    if (OUT_BF16) {
+      reinterpret_cast<unsigned int*>(y)[row * (d / 2) + lane + 64 * j] = pack2bf(o0, o1);
+    } else {
+      reinterpret_cast<float2*>(y)[row * (d / 2) + lane + 64 * j] = make_float2(o0, o1);
+    }
+  }
+}
+
+template <bool OUT_BF16>
+static int ln_dispatch(const float* x, long row_stride, const float* w, const float* b, void* y, long M,
+                       int d, hipStream_t s) {
+  GWW_REQUIRE(d % 128 == 0 && d >= 128 && d <= 1280, "layernorm: d=%d must be a multiple of 128 <= 1280", d);
+  if (M == 0) return GWW_OK;
+  dim3 grid((unsigned)cdiv(M, 4)), block(256);
+#define GWW_LN_CASE(NV)                                                                          \
+  case NV:                                                                                       \
+    hipLaunchKernelGGL((k_layernorm<NV, OUT_BF16>), grid, block, 0, s, x, row_stride, w, b, y, M); \
+    break;
+  switch (d / 128) {
+    GWW_LN_CASE(1) GWW_LN_CASE(2) GWW_LN_CASE(3) GWW_LN_CASE(4) GWW_LN_CASE(5)
+    GWW_LN_CASE(6) GWW_LN_CASE(7) GWW_LN_CASE(8) GWW_LN_CASE(9) GWW_LN_CASE(10)
+  }
+#undef GWW_LN_CASE
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+int launch_layernorm(const float* x, const float* w, const float* b, void* y, int out_bf16, long M, int d,
+                     hipStream_t s) {
+  return out_bf16 ? ln_dispatch<true>(x, d, w, b, y, M, d, s) : ln_dispatch<false>(x, d, w, b, y, M, d, s);
+}
+
+// fp32 LayerNorm of M rows spaced row_stride apart (the last-token fast path:
+// only row 1499 of every segment is consumed, Signal_vs_Noise/src/model.py:25-26)
+int launch_layernorm_rows(const float* x, long row_stride, const float* w, const float* b, float* y,
+                          long M, int d, hipStream_t s) {
+  return ln_dispatch<false>(x, row_stride, w, b, y, M, d, s);
+}
+
+// ---------------------------------------------------------------- casts / packing
+__global__ __launch_bounds__(256) void k_cast_f32_bf16(const float* __restrict__ x,
+                                                       unsigned short* __restrict__ y, long n) {
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long step = (long)gridDim.x * 256 * 4;
+  for (; i + 3 < n; i += step) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    u32x2 o = {pack2bf(v.x, v.y), pack2bf(v.z, v.w)};
+    *reinterpret_cast<u32x2*>(y + i) = o;
+  }
+  // tail (n not a multiple of 4): the last partial group
+  if (i < n && i + 3 >= n) {
+    for (long j = i; j < n; ++j) y[j] = f2bf(x[j]);
+  }
+}
+
+int launch_cast_f32_bf16(const float* x, void* y, long n, hipStream_t s) {
+  if (n == 0) return GWW_OK;
+  GWW_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0, "cast: pointers must be 16/8-byte aligned");
+  long blocks = cdiv(cdiv(n, 4), 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_cast_f32_bf16, dim3((unsigned)blocks), dim3(256), 0, s, x,
+                     reinterpret_cast<unsigned short*>(y), n);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+// Pack a [N, C, taps] fp32 weight (taps = 1 for linears, 3 for the convs) into the
+// kernel layout [N, Kpad] with k = tap * C + c, zero for k >= taps*C, scaled.
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, OutT* __restrict__ out,
+                                                     int N, int C, int taps, int Kpad, float scale) {
+  const long total = (long)N * Kpad;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / Kpad), k = (int)(i - (long)n * Kpad);
+    float v = 0.f;
+    if (k < taps * C) {
+      const int tap = k / C, c = k - tap * C;
+      v = w[((long)n * C + c) * taps + tap] * scale;
+    }
+    if constexpr (sizeof(OutT) == 2) {
+      out[i] = f2bf(v);
+    } else {
+      out[i] = v;
+    }
+  }
+}
+
+int launch_pack_weight(const float* w, void* out, int out_bf16, int N, int C, int taps, int Kpad,
+                       float scale, hipStream_t s) {
+  long blocks = cdiv((long)N * Kpad, 256);
+  if (blocks > 4096) blocks = 4096;
+  if (out_bf16)
+    hipLaunchKernelGGL(k_pack_weight<unsigned short>, dim3((unsigned)blocks), dim3(256), 0, s, w,
+                       reinterpret_cast<unsigned short*>(out), N, C, taps, Kpad, scale);
+  else
+    hipLaunchKernelGGL(k_pack_weight<float>, dim3((unsigned)blocks), dim3(256), 0, s, w,
+                       reinterpret_cast<float*>(out), N, C, taps, Kpad, scale);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+// out[i] = in ? in[i] * scale : 0
+__global__ __launch_bounds__(256) void k_scale_copy(const float* __restrict__ in, float* __restrict__ out,
+                                                    int n, float scale) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = in ? in[i] * scale : 0.f;
+}
+
+int launch_scale_copy(const float* in, float* out, int n, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, in, out, n, scale);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+// ---------------------------------------------------------------- DoRA merge (K11)
+// peft 0.12.0 tuners/lora/dora.py: W' = W0 + s B A ; n = ||W'||_2 per output row ;
+// W_eff = (m / n)[:, None] * W'.  One workgroup per output row; fp32.
+__global__ __launch_bounds__(256) void k_dora_merge(const float* __restrict__ w0, const float* __restrict__ a,
+                                                    const float* __restrict__ b, const float* __restrict__ m,
+                                                    float scaling, int d_in, int r, float* __restrict__ w_eff,
+                                                    float* __restrict__ norm_out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [r] scaled B row, then [4] partials
+  float* brow = sm;
+  float* red = sm + r;
+  const int row = blockIdx.x;
+  for (int j = threadIdx.x; j < r; j += 256) brow[j] = scaling * b[(long)row * r + j];
+  __syncthreads();
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < d_in; c += 256) {
+    float v = w0[(long)row * d_in + c];
+    for (int j = 0; j < r; ++j) v = fmaf(brow[j], a[(long)j * d_in + c], v);
+    w_eff[(long)row * d_in + c] = v;       // W' for now; rescaled below
+    ss = fmaf(v, v, ss);
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+  const float g = m[row] / nrm;
+  if (threadIdx.x == 0 && norm_out) norm_out[row] = nrm;
+  for (int c = threadIdx.x; c < d_in; c += 256) w_eff[(long)row * d_in + c] *= g;   // same thread wrote it
+}
+
+}  // namespace gww
+
+using namespace gww;
+
+extern "C" int gww_dora_merge_f32(const float* w0, const float* a, const float* b, const float* m,
+                                  float scaling, int d_out, int d_in, int r, float* w_eff,
+                                  float* norm_out, void* stream) {
+  GWW_REQUIRE(w0 && a && b && m && w_eff, "gww_dora_merge_f32: NULL argument");
+  GWW_REQUIRE(d_out > 0 && d_in > 0 && r > 0 && r <= 1024, "gww_dora_merge_f32: bad shape %dx%d r=%d", d_out, d_in, r);
+  hipLaunchKernelGGL(k_dora_merge, dim3((unsigned)d_out), dim3(256), (r + 4) * sizeof(float),
+                     (hipStream_t)stream, w0, a, b, m, scaling, d_in, r, w_eff, norm_out);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+extern "C" int gww_layernorm(const float* x, const float* w, const float* b, void* y, int out_bf16, long M,
+                             int d, void* stream) {
+  GWW_REQUIRE(x && w && b && y, "gww_layernorm: NULL argument");
+  GWW_REQUIRE(M >= 0, "gww_layernorm: M < 0");
+  return launch_layernorm(x, w, b, y, out_bf16, M, d, (hipStream_t)stream);
+}
+
+extern "C" int gww_cast_f32_bf16(const float* x, void* y, long n, void* stream) {
+  GWW_REQUIRE(x && y && n >= 0, "gww_cast_f32_bf16: bad argument");
+  return launch_cast_f32_bf16(x, y, n, (hipStream_t)stream);
+}
+
+extern "C" int gww_version(void) { return GWW_VERSION; }
+extern "C" const char* gww_last_error(void) { return g_err; }

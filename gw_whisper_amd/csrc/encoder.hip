@@ -1,0 +1,289 @@
+// Encoder handle: weight packing + the forward launch sequence (host side of the
+// C ABI).  Replaces WhisperEncoder.forward (HF:modeling_whisper.py:592-646):
+//   conv1+GELU -> conv2(stride 2)+GELU + pos -> L x [LN, QKV, MHSA, out_proj+res,
+//   LN, fc1+GELU, fc2+res] -> final LN.
+//
+// HBM layout of one forward (batch B, T_in = 3000 frames, T = 1500 tokens):
+//   melT  [B, T_in+2, 80]   token-major mel, zero rows = Conv1d padding   (+tail pad)
+//   c1    [B, T_in+2, d]    conv1 output, token-major, zero rows = padding (+1 row)
+//   x     [B*T, d]   fp32   residual stream (never leaves fp32)
+//   h     [B*T, d]          LayerNorm output (GEMM A operand)
+//   qkv   [B*T, 3d]         q | k | v, q pre-scaled by 1/8
+//   ctx   [B*T, d]          attention context
+//   f1    [B*T, ffn]        fc1 + GELU
+// In GWW_PREC_BF16 the activation tensors other than x are bf16; in GWW_PREC_F32
+// everything is fp32.  All of it lives in the caller's workspace; the handle owns
+// only the packed weights.
+#include "common.h"
+#include "epilogue.h"
+
+#include <vector>
+
+namespace gww {
+int launch_mel_to_tokens(const float* mel, void* out, int out_bf16, int B, int C, int T, hipStream_t s);
+}
+
+using namespace gww;
+
+namespace {
+
+struct LayerW {
+  // bf16 panels
+  unsigned short *wqkv, *wo, *w1, *w2;
+  // fp32 panels (parity path)
+  float *wqkv32, *wo32, *w132, *w232;
+  float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
+};
+
+constexpr int kConv1Kpad = 256;   // 3 * 80 = 240 padded to a multiple of 64
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+struct gww_encoder {
+  gww_enc_cfg cfg{};
+  bool ready = false;
+  char* blob = nullptr;
+  size_t blob_bytes = 0;
+  unsigned short *c1w = nullptr, *c2w = nullptr;
+  float *c1w32 = nullptr, *c2w32 = nullptr;
+  float *c1b = nullptr, *c2b = nullptr, *pos = nullptr, *lnw = nullptr, *lnb = nullptr;
+  std::vector<LayerW> layers;
+};
+
+extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
+  GWW_REQUIRE(cfg && out, "gww_encoder_create: NULL argument");
+  const int d = cfg->d_model, L = cfg->n_layers, H = cfg->n_heads, F = cfg->ffn, C = cfg->n_mels;
+  GWW_REQUIRE(d > 0 && d % 128 == 0 && d <= 1280, "gww_encoder_create: d_model=%d must be a multiple of 128 <= 1280", d);
+  GWW_REQUIRE(H * 64 == d, "gww_encoder_create: n_heads=%d * 64 != d_model=%d (Whisper head_dim is 64)", H, d);
+  GWW_REQUIRE(L > 0 && F > 0 && F % 64 == 0, "gww_encoder_create: bad n_layers=%d / ffn=%d", L, F);
+  GWW_REQUIRE(C == 80, "gww_encoder_create: n_mels=%d (only 80 is supported)", C);
+  GWW_REQUIRE(cfg->t_in > 0 && cfg->t_in % 2 == 0, "gww_encoder_create: t_in=%d must be even", cfg->t_in);
+  const int T = cfg->t_in / 2;
+
+  gww_encoder* e = new gww_encoder();
+  e->cfg = *cfg;
+  // carve one allocation
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+  const size_t o_c1w = take((size_t)d * kConv1Kpad * 2), o_c2w = take((size_t)d * 3 * d * 2);
+  const size_t o_c1w32 = take((size_t)d * kConv1Kpad * 4), o_c2w32 = take((size_t)d * 3 * d * 4);
+  const size_t o_c1b = take(d * 4), o_c2b = take(d * 4), o_pos = take((size_t)T * d * 4);
+  const size_t o_lnw = take(d * 4), o_lnb = take(d * 4);
+  struct LO { size_t wqkv, wo, w1, w2, wqkv32, wo32, w132, w232, bqkv, bo, b1, b2, ln1w, ln1b, ln2w, ln2b; };
+  std::vector<LO> lo(L);
+  for (int i = 0; i < L; ++i) {
+    lo[i].wqkv = take((size_t)3 * d * d * 2);
+    lo[i].wo = take((size_t)d * d * 2);
+    lo[i].w1 = take((size_t)F * d * 2);
+    lo[i].w2 = take((size_t)d * F * 2);
+    lo[i].wqkv32 = take((size_t)3 * d * d * 4);
+    lo[i].wo32 = take((size_t)d * d * 4);
+    lo[i].w132 = take((size_t)F * d * 4);
+    lo[i].w232 = take((size_t)d * F * 4);
+    lo[i].bqkv = take(3 * d * 4);
+    lo[i].bo = take(d * 4);
+    lo[i].b1 = take(F * 4);
+    lo[i].b2 = take(d * 4);
+    lo[i].ln1w = take(d * 4);
+    lo[i].ln1b = take(d * 4);
+    lo[i].ln2w = take(d * 4);
+    lo[i].ln2b = take(d * 4);
+  }
+  hipError_t err = hipMalloc(&e->blob, off);
+  if (err != hipSuccess) {
+    delete e;
+    return fail(GWW_ERR_HIP, "hipMalloc(%zu bytes of packed weights) failed: %s", off, hipGetErrorString(err));
+  }
+  e->blob_bytes = off;
+  char* p = e->blob;
+  e->c1w = (unsigned short*)(p + o_c1w);
+  e->c2w = (unsigned short*)(p + o_c2w);
+  e->c1w32 = (float*)(p + o_c1w32);
+  e->c2w32 = (float*)(p + o_c2w32);
+  e->c1b = (float*)(p + o_c1b);
+  e->c2b = (float*)(p + o_c2b);
+  e->pos = (float*)(p + o_pos);
+  e->lnw = (float*)(p + o_lnw);
+  e->lnb = (float*)(p + o_lnb);
+  e->layers.resize(L);
+  for (int i = 0; i < L; ++i) {
+    LayerW& w = e->layers[i];
+    w.wqkv = (unsigned short*)(p + lo[i].wqkv);
+    w.wo = (unsigned short*)(p + lo[i].wo);
+    w.w1 = (unsigned short*)(p + lo[i].w1);
+    w.w2 = (unsigned short*)(p + lo[i].w2);
+    w.wqkv32 = (float*)(p + lo[i].wqkv32);
+    w.wo32 = (float*)(p + lo[i].wo32);
+    w.w132 = (float*)(p + lo[i].w132);
+    w.w232 = (float*)(p + lo[i].w232);
+    w.bqkv = (float*)(p + lo[i].bqkv);
+    w.bo = (float*)(p + lo[i].bo);
+    w.b1 = (float*)(p + lo[i].b1);
+    w.b2 = (float*)(p + lo[i].b2);
+    w.ln1w = (float*)(p + lo[i].ln1w);
+    w.ln1b = (float*)(p + lo[i].ln1b);
+    w.ln2w = (float*)(p + lo[i].ln2w);
+    w.ln2b = (float*)(p + lo[i].ln2b);
+  }
+  *out = e;
+  return GWW_OK;
+}
+
+extern "C" void gww_encoder_destroy(gww_encoder* e) {
+  if (!e) return;
+  if (e->blob) (void)hipFree(e->blob);
+  delete e;
+}
+
+#define GWW_TRY(expr)          \
+  do {                         \
+    int _rc = (expr);          \
+    if (_rc != GWW_OK) return _rc; \
+  } while (0)
+
+extern "C" int gww_encoder_set_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_layer* layers,
+                                       int n_layers, void* stream) {
+  GWW_REQUIRE(e && g && layers, "gww_encoder_set_weights: NULL argument");
+  GWW_REQUIRE(n_layers == e->cfg.n_layers, "gww_encoder_set_weights: got %d layers, handle has %d", n_layers,
+              e->cfg.n_layers);
+  GWW_REQUIRE(g->conv1_w && g->conv1_b && g->conv2_w && g->conv2_b && g->pos && g->ln_w && g->ln_b,
+              "gww_encoder_set_weights: NULL global weight");
+  hipStream_t s = (hipStream_t)stream;
+  const int d = e->cfg.d_model, F = e->cfg.ffn, C = e->cfg.n_mels, T = e->cfg.t_in / 2;
+  const float qs = 0.125f;   // head_dim^-0.5 = 64^-0.5, exact power of two (HF:modeling_whisper.py:309)
+  auto pack = [&](const float* w, unsigned short* o16, float* o32, int N, int Cin, int taps, int Kpad,
+                  float scale) -> int {
+    GWW_TRY(launch_pack_weight(w, o16, 1, N, Cin, taps, Kpad, scale, s));
+    GWW_TRY(launch_pack_weight(w, o32, 0, N, Cin, taps, Kpad, scale, s));
+    return GWW_OK;
+  };
+  GWW_TRY(pack(g->conv1_w, e->c1w, e->c1w32, d, C, 3, kConv1Kpad, 1.f));
+  GWW_TRY(pack(g->conv2_w, e->c2w, e->c2w32, d, d, 3, 3 * d, 1.f));
+  GWW_TRY(launch_scale_copy(g->conv1_b, e->c1b, d, 1.f, s));
+  GWW_TRY(launch_scale_copy(g->conv2_b, e->c2b, d, 1.f, s));
+  GWW_HIP(hipMemcpyAsync(e->pos, g->pos, (size_t)T * d * 4, hipMemcpyDeviceToDevice, s));
+  GWW_TRY(launch_scale_copy(g->ln_w, e->lnw, d, 1.f, s));
+  GWW_TRY(launch_scale_copy(g->ln_b, e->lnb, d, 1.f, s));
+  for (int i = 0; i < n_layers; ++i) {
+    const gww_enc_layer& L = layers[i];
+    LayerW& w = e->layers[i];
+    GWW_REQUIRE(L.ln1_w && L.ln1_b && L.q_w && L.q_b && L.k_w && L.v_w && L.v_b && L.o_w && L.o_b && L.ln2_w &&
+                    L.ln2_b && L.fc1_w && L.fc1_b && L.fc2_w && L.fc2_b,
+                "gww_encoder_set_weights: NULL weight in layer %d", i);
+    const size_t dd = (size_t)d * d;
+    GWW_TRY(pack(L.q_w, w.wqkv, w.wqkv32, d, d, 1, d, qs));
+    GWW_TRY(pack(L.k_w, w.wqkv + dd, w.wqkv32 + dd, d, d, 1, d, 1.f));
+    GWW_TRY(pack(L.v_w, w.wqkv + 2 * dd, w.wqkv32 + 2 * dd, d, d, 1, d, 1.f));
+    GWW_TRY(pack(L.o_w, w.wo, w.wo32, d, d, 1, d, 1.f));
+    GWW_TRY(pack(L.fc1_w, w.w1, w.w132, F, d, 1, d, 1.f));
+    GWW_TRY(pack(L.fc2_w, w.w2, w.w232, d, F, 1, F, 1.f));
+    GWW_TRY(launch_scale_copy(L.q_b, w.bqkv, d, qs, s));
+    GWW_TRY(launch_scale_copy(nullptr, w.bqkv + d, d, 0.f, s));   // k_proj has no bias
+    GWW_TRY(launch_scale_copy(L.v_b, w.bqkv + 2 * d, d, 1.f, s));
+    GWW_TRY(launch_scale_copy(L.o_b, w.bo, d, 1.f, s));
+    GWW_TRY(launch_scale_copy(L.fc1_b, w.b1, F, 1.f, s));
+    GWW_TRY(launch_scale_copy(L.fc2_b, w.b2, d, 1.f, s));
+    GWW_TRY(launch_scale_copy(L.ln1_w, w.ln1w, d, 1.f, s));
+    GWW_TRY(launch_scale_copy(L.ln1_b, w.ln1b, d, 1.f, s));
+    GWW_TRY(launch_scale_copy(L.ln2_w, w.ln2w, d, 1.f, s));
+    GWW_TRY(launch_scale_copy(L.ln2_b, w.ln2b, d, 1.f, s));
+  }
+  e->ready = true;
+  return GWW_OK;
+}
+
+namespace {
+struct WsLayout {
+  size_t melT, c1, x, h, qkv, ctx, f1, total;
+};
+WsLayout ws_layout(const gww_enc_cfg& c, int B, int precision) {
+  const size_t es = precision == GWW_PREC_BF16 ? 2 : 4;
+  const size_t d = c.d_model, F = c.ffn, Tin = c.t_in, T = c.t_in / 2, C = c.n_mels;
+  WsLayout w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+  w.melT = take(((size_t)B * (Tin + 2) * C + kConv1Kpad) * es);
+  w.c1 = take(((size_t)B * (Tin + 2) + 2) * d * es);
+  w.x = take((size_t)B * T * d * 4);
+  w.h = take((size_t)B * T * d * es);
+  w.qkv = take((size_t)B * T * 3 * d * es);
+  w.ctx = take((size_t)B * T * d * es);
+  w.f1 = take((size_t)B * T * F * es);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t gww_encoder_workspace_bytes(const gww_encoder* e, int batch, int precision) {
+  if (!e || batch <= 0) return 0;
+  return ws_layout(e->cfg, batch, precision).total;
+}
+
+extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, int precision, void* workspace,
+                                   size_t workspace_bytes, float* last_hidden, float* last_token,
+                                   void* stream) {
+  GWW_REQUIRE(e && mel, "gww_encoder_forward: NULL argument");
+  if (!e->ready) return fail(GWW_ERR_STATE, "gww_encoder_forward: weights not set");
+  GWW_REQUIRE(precision == GWW_PREC_BF16 || precision == GWW_PREC_F32, "gww_encoder_forward: bad precision %d",
+              precision);
+  GWW_REQUIRE(batch >= 0, "gww_encoder_forward: batch < 0");
+  GWW_REQUIRE(last_hidden || last_token, "gww_encoder_forward: no output requested");
+  if (batch == 0) return GWW_OK;
+  GWW_REQUIRE((((uintptr_t)mel) & 15) == 0 && (((uintptr_t)workspace) & 255) == 0,
+              "gww_encoder_forward: mel must be 16-byte and workspace 256-byte aligned");
+  const WsLayout w = ws_layout(e->cfg, batch, precision);
+  if (!workspace || workspace_bytes < w.total)
+    return fail(GWW_ERR_WORKSPACE, "gww_encoder_forward: workspace %zu bytes < required %zu", workspace_bytes,
+                w.total);
+  hipStream_t s = (hipStream_t)stream;
+  const bool bf = precision == GWW_PREC_BF16;
+  const size_t es = bf ? 2 : 4;
+  const int d = e->cfg.d_model, F = e->cfg.ffn, Tin = e->cfg.t_in, T = Tin / 2, C = e->cfg.n_mels, H = e->cfg.n_heads;
+  const int B = batch;
+  char* base = (char*)workspace;
+  void* melT = base + w.melT;
+  void* c1 = base + w.c1;
+  float* x = (float*)(base + w.x);
+  void* h = base + w.h;
+  void* qkv = base + w.qkv;
+  void* ctx = base + w.ctx;
+  void* f1 = base + w.f1;
+  const long M = (long)B * T;
+
+  // generic GEMM dispatch on precision
+  auto gemm = [&](const void* A, long lda, const void* W16, const float* W32, const float* bias,
+                  const float* resid, const float* pos, void* Cout, long Mr, int N, int K, int epi,
+                  int rpb) -> int {
+    return bf ? launch_gemm_bf16(A, lda, W16, bias, resid, pos, Cout, Mr, N, K, epi, rpb, s)
+              : launch_gemm_f32((const float*)A, lda, W32, bias, resid, pos, (float*)Cout, Mr, N, K, epi, rpb, s);
+  };
+
+  // ---- stem
+  GWW_TRY(launch_mel_to_tokens(mel, melT, bf ? 1 : 0, B, C, Tin, s));
+  GWW_HIP(hipMemsetAsync((char*)melT + (size_t)B * (Tin + 2) * C * es, 0, kConv1Kpad * es, s));
+  GWW_HIP(hipMemsetAsync(c1, 0, (size_t)d * es, s));   // zero row 0 of batch 0 (token -1)
+  GWW_TRY(gemm(melT, C, e->c1w, e->c1w32, e->c1b, nullptr, nullptr, c1, (long)B * (Tin + 2), d, kConv1Kpad,
+               EPI_CONV1, Tin + 2));
+  GWW_TRY(gemm(c1, 2L * d, e->c2w, e->c2w32, e->c2b, nullptr, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2,
+               T + 1));
+  // ---- layers
+  for (int i = 0; i < e->cfg.n_layers; ++i) {
+    const LayerW& L = e->layers[i];
+    GWW_TRY(launch_layernorm(x, L.ln1w, L.ln1b, h, bf ? 1 : 0, M, d, s));
+    GWW_TRY(gemm(h, d, L.wqkv, L.wqkv32, L.bqkv, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0));
+    if (bf) GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s));
+    else GWW_TRY(launch_attention_f32((const float*)qkv, (float*)ctx, B, T, H, s));
+    GWW_TRY(gemm(ctx, d, L.wo, L.wo32, L.bo, x, nullptr, x, M, d, d, EPI_RESID, 0));
+    GWW_TRY(launch_layernorm(x, L.ln2w, L.ln2b, h, bf ? 1 : 0, M, d, s));
+    GWW_TRY(gemm(h, d, L.w1, L.w132, L.b1, nullptr, nullptr, f1, M, F, d, EPI_GELU, 0));
+    GWW_TRY(gemm(f1, F, L.w2, L.w232, L.b2, x, nullptr, x, M, d, F, EPI_RESID, 0));
+  }
+  // ---- final LayerNorm (HF:modeling_whisper.py:642); callers pool token T-1
+  // (Signal_vs_Noise/src/model.py:25-26), so that row alone is a separate fast output
+  if (last_hidden) GWW_TRY(launch_layernorm(x, e->lnw, e->lnb, last_hidden, 0, M, d, s));
+  if (last_token)
+    GWW_TRY(launch_layernorm_rows(x + (long)(T - 1) * d, (long)T * d, e->lnw, e->lnb, last_token, B, d, s));
+  return GWW_OK;
+}

@@ -1,0 +1,279 @@
+// Log-mel front end (K1 + K2 of SURVEY.md section 2.1) for gfx950.
+//
+// Replaces WhisperFeatureExtractor.__call__ (reference call sites
+// Signal_vs_Noise/src/dataset.py:20-21; HF:feature_extraction_whisper.py:135-168):
+//   zero-pad to 480000 -> reflect-pad 200 -> 400-pt periodic-Hann DFT, hop 160 ->
+//   |X|^2 (frames 0..2999) -> mel[80,201] @ P -> log10(max(.,1e-10)) ->
+//   per-segment max -> max(x, max-8) -> (x+4)/4.
+//
+// HBM-bound: 64 KB in + 960 KB out per segment.  Two kernels:
+//   k_logmel_frames    DFT + mel + log10 for the LIVE frames only (frames that can
+//                      see a non-zero sample: ceil((n+200)/160), 102 for 1 s), raw
+//                      log-mel written in place, per-segment max via atomicMax
+//   k_logmel_finalize  streams the whole [80,3000] row: clamp to max-8, affine,
+//                      constant fill of the dead frames (float4 stores)
+// The DFT uses the real-input symmetry x[n] +- x[400-n] (half the MACs) with the
+// 400-entry twiddle table and the windowed frames in LDS; fp32 throughout.
+#include "common.h"
+
+#include <math.h>
+#include <vector>
+
+namespace gww {
+
+constexpr int kNfft = 400;
+constexpr int kHop = 160;
+constexpr int kNfreq = 201;
+constexpr int kNmel = 80;
+constexpr int kFrames = 3000;
+constexpr int kChunk = 480000;
+constexpr int kFT = 8;                      // frames per workgroup
+constexpr int kSpan = kHop * (kFT - 1) + kNfft;  // 1520 samples per tile
+
+struct Tables {
+  float* win;      // [400]
+  float* cost;     // [400] cos(2 pi k / 400)
+  float* sint;     // [400]
+  float* fbT;      // [201][80] filterbank, transposed so consecutive mels are contiguous
+};
+
+__device__ __forceinline__ unsigned int fkey(float f) {
+  unsigned int b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned int k) {
+  unsigned int b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(b);
+}
+
+// grid (tiles, n_seg), 256 threads
+__global__ __launch_bounds__(256) void k_logmel_frames(const float* __restrict__ wave, long stride,
+                                                       int n_eff, int live, Tables tb,
+                                                       float* __restrict__ out,
+                                                       unsigned int* __restrict__ seg_max) {
+  __shared__ __attribute__((aligned(16))) float xs[kSpan];
+  __shared__ __attribute__((aligned(16))) float ev[kFT][204];   // ev[f][0..200]
+  __shared__ __attribute__((aligned(16))) float od[kFT][204];   // od[f][0..199], od[.][0]=0
+  __shared__ float ct[kNfft];
+  __shared__ float st[kNfft];
+  __shared__ float pw[kFT][kNfreq + 3];
+  __shared__ float red[4];
+
+  const int tid = threadIdx.x;
+  const int seg = blockIdx.y;
+  const int t0 = blockIdx.x * kFT;
+  const float* x = wave + (long)seg * stride;
+
+  // stage the samples of this tile (reflect at both ends of the 480000 buffer, zeros past n_eff)
+  for (int i = tid; i < kSpan; i += 256) {
+    int p = t0 * kHop - kNfft / 2 + i;       // index into the unpadded 480000 buffer
+    if (p < 0) p = -p;
+    if (p >= kChunk) p = 2 * (kChunk - 1) - p;
+    xs[i] = (p < n_eff) ? x[p] : 0.0f;
+  }
+  for (int i = tid; i < kNfft; i += 256) {
+    ct[i] = tb.cost[i];
+    st[i] = tb.sint[i];
+  }
+  __syncthreads();
+  // windowed even / odd parts
+  for (int i = tid; i < kFT * 204; i += 256) {
+    int f = i / 204, n = i - f * 204;
+    float e = 0.f, o = 0.f;
+    if (n <= 200) {
+      float a = xs[f * kHop + n] * tb.win[n];
+      if (n == 0 || n == 200) {
+        e = a;
+      } else {
+        float b = xs[f * kHop + kNfft - n] * tb.win[kNfft - n];
+        e = a + b;
+        o = a - b;
+      }
+    }
+    ev[f][n] = e;
+    od[f][n] = o;
+  }
+  __syncthreads();
+
+  if (tid < kNfreq) {
+    const int k = tid;
+    float re[kFT], im[kFT];
+#pragma unroll
+    for (int f = 0; f < kFT; ++f) re[f] = im[f] = 0.f;
+    int idx = 0;  // (k * n) mod 400
+    for (int n = 0; n < 204; n += 4) {
+      float c[4], s[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c[j] = ct[idx];
+        s[j] = st[idx];
+        idx += k;
+        if (idx >= kNfft) idx -= kNfft;
+      }
+#pragma unroll
+      for (int f = 0; f < kFT; ++f) {
+        const float4 e4 = *reinterpret_cast<const float4*>(&ev[f][n]);
+        const float4 o4 = *reinterpret_cast<const float4*>(&od[f][n]);
+        re[f] = fmaf(e4.x, c[0], re[f]);
+        re[f] = fmaf(e4.y, c[1], re[f]);
+        re[f] = fmaf(e4.z, c[2], re[f]);
+        re[f] = fmaf(e4.w, c[3], re[f]);
+        im[f] = fmaf(o4.x, s[0], im[f]);
+        im[f] = fmaf(o4.y, s[1], im[f]);
+        im[f] = fmaf(o4.z, s[2], im[f]);
+        im[f] = fmaf(o4.w, s[3], im[f]);
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < kFT; ++f) pw[f][k] = re[f] * re[f] + im[f] * im[f];
+  }
+  __syncthreads();
+
+  // mel projection + log10; thread -> (frame, mel) pairs, mel fastest for coalesced fbT reads
+  float lmax = -INFINITY;
+  for (int i = tid; i < kFT * kNmel; i += 256) {
+    const int f = i / kNmel, m = i - f * kNmel;
+    const int t = t0 + f;
+    float acc = 0.f;
+    for (int k = 0; k < kNfreq; ++k) acc = fmaf(tb.fbT[k * kNmel + m], pw[f][k], acc);
+    // log10 in fp64, rounded once: ocml's log10f is 1 ulp off at 1e-10 (-10.000001) where
+    // torch (and the oracle) give the correctly rounded -10.0 that the dead frames use
+    const float lg = (float)log10((double)fmaxf(acc, 1e-10f));
+    if (t < live) {
+      out[((long)seg * kNmel + m) * kFrames + t] = lg;
+      lmax = fmaxf(lmax, lg);
+    }
+  }
+  lmax = wave_max(lmax);
+  if ((tid & 63) == 0) red[tid >> 6] = lmax;
+  __syncthreads();
+  if (tid == 0) {
+    float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > -INFINITY) atomicMax(&seg_max[seg], fkey(m));
+  }
+}
+
+// grid (80, n_seg), 256 threads: one [3000] row per workgroup
+__global__ __launch_bounds__(256) void k_logmel_finalize(float* __restrict__ out, int live,
+                                                         const unsigned int* __restrict__ seg_max) {
+  const int seg = blockIdx.y, m = blockIdx.x;
+  float mx = fkey_inv(seg_max[seg]);
+  mx = fmaxf(mx, live < kFrames ? -10.0f : mx);     // dead frames contribute log10(1e-10) = -10
+  const float floor_v = mx - 8.0f;
+  const float padv = (fmaxf(-10.0f, floor_v) + 4.0f) * 0.25f;
+  float4* row = reinterpret_cast<float4*>(out + ((long)seg * kNmel + m) * kFrames);
+  for (int i = threadIdx.x; i < kFrames / 4; i += 256) {
+    const int t = i * 4;
+    float4 v;
+    if (t + 3 < live) {
+      v = row[i];
+      v.x = (fmaxf(v.x, floor_v) + 4.0f) * 0.25f;
+      v.y = (fmaxf(v.y, floor_v) + 4.0f) * 0.25f;
+      v.z = (fmaxf(v.z, floor_v) + 4.0f) * 0.25f;
+      v.w = (fmaxf(v.w, floor_v) + 4.0f) * 0.25f;
+    } else if (t >= live) {
+      v = make_float4(padv, padv, padv, padv);
+    } else {
+      v = row[i];
+      v.x = (t + 0 < live) ? (fmaxf(v.x, floor_v) + 4.0f) * 0.25f : padv;
+      v.y = (t + 1 < live) ? (fmaxf(v.y, floor_v) + 4.0f) * 0.25f : padv;
+      v.z = (t + 2 < live) ? (fmaxf(v.z, floor_v) + 4.0f) * 0.25f : padv;
+      v.w = (t + 3 < live) ? (fmaxf(v.w, floor_v) + 4.0f) * 0.25f : padv;
+    }
+    row[i] = v;
+  }
+}
+
+// ---- host side: tables (HF:audio_utils.py:448-520,638-731 slaney scale + norm) ----
+static double hz2mel(double f) {
+  return f >= 1000.0 ? 15.0 + log(f / 1000.0) * (27.0 / log(6.4)) : 3.0 * f / 200.0;
+}
+static double mel2hz(double m) {
+  return m >= 15.0 ? 1000.0 * exp((log(6.4) / 27.0) * (m - 15.0)) : 200.0 * m / 3.0;
+}
+
+}  // namespace gww
+
+using namespace gww;
+
+struct gww_frontend {
+  Tables tb{};
+  float* blob = nullptr;
+};
+
+extern "C" int gww_frontend_create(gww_frontend** out) {
+  GWW_REQUIRE(out != nullptr, "gww_frontend_create: out is NULL");
+  std::vector<float> h(3 * kNfft + kNfreq * kNmel);
+  const double pi = 3.14159265358979323846;
+  for (int k = 0; k < kNfft; ++k) {
+    h[k] = (float)(0.5 - 0.5 * cos(2.0 * pi * k / kNfft));  // torch.hann_window(400) periodic
+    h[kNfft + k] = (float)cos(2.0 * pi * k / kNfft);
+    h[2 * kNfft + k] = (float)sin(2.0 * pi * k / kNfft);
+  }
+  // filterbank [201][80] (already "transposed" relative to mel.T @ P)
+  const double mel_min = hz2mel(0.0), mel_max = hz2mel(8000.0);
+  std::vector<double> ff(kNmel + 2);
+  for (int i = 0; i < kNmel + 2; ++i) ff[i] = mel2hz(mel_min + (mel_max - mel_min) * i / (kNmel + 1));
+  for (int k = 0; k < kNfreq; ++k) {
+    const double fk = 8000.0 * k / (kNfreq - 1);
+    for (int m = 0; m < kNmel; ++m) {
+      const double down = (fk - ff[m]) / (ff[m + 1] - ff[m]);
+      const double up = (ff[m + 2] - fk) / (ff[m + 2] - ff[m + 1]);
+      double v = down < up ? down : up;
+      if (v < 0) v = 0;
+      v *= 2.0 / (ff[m + 2] - ff[m]);
+      h[3 * kNfft + k * kNmel + m] = (float)v;
+    }
+  }
+  gww_frontend* fe = new gww_frontend();
+  hipError_t e = hipMalloc(&fe->blob, h.size() * sizeof(float));
+  if (e != hipSuccess) {
+    delete fe;
+    return fail(GWW_ERR_HIP, "hipMalloc(frontend tables) failed: %s", hipGetErrorString(e));
+  }
+  e = hipMemcpy(fe->blob, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(fe->blob);
+    delete fe;
+    return fail(GWW_ERR_HIP, "hipMemcpy(frontend tables) failed: %s", hipGetErrorString(e));
+  }
+  fe->tb.win = fe->blob;
+  fe->tb.cost = fe->blob + kNfft;
+  fe->tb.sint = fe->blob + 2 * kNfft;
+  fe->tb.fbT = fe->blob + 3 * kNfft;
+  *out = fe;
+  return GWW_OK;
+}
+
+extern "C" void gww_frontend_destroy(gww_frontend* fe) {
+  if (!fe) return;
+  if (fe->blob) (void)hipFree(fe->blob);
+  delete fe;
+}
+
+extern "C" int gww_logmel_f32(gww_frontend* fe, const float* wave, int n_seg, int n_samples,
+                              long wave_stride, float* out, float* seg_max, void* stream) {
+  GWW_REQUIRE(fe && wave && out && seg_max, "gww_logmel_f32: NULL argument");
+  GWW_REQUIRE(n_seg >= 0 && n_samples >= 0, "gww_logmel_f32: negative size");
+  GWW_REQUIRE(wave_stride >= (n_samples < kChunk ? n_samples : kChunk),
+              "gww_logmel_f32: wave_stride %ld < n_samples %d", wave_stride, n_samples);
+  if (n_seg == 0) return GWW_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int n_eff = n_samples < kChunk ? n_samples : kChunk;   // HF truncates at 30 s
+  int live = kFrames;
+  if (n_eff < kChunk - kNfft) {
+    live = (n_eff + kNfft / 2 + kHop - 1) / kHop;
+    if (live > kFrames) live = kFrames;
+    if (live < 1) live = 1;
+  }
+  GWW_HIP(hipMemsetAsync(seg_max, 0, sizeof(float) * (size_t)n_seg, s));
+  dim3 g1((unsigned)cdiv(live, kFT), (unsigned)n_seg);
+  hipLaunchKernelGGL(k_logmel_frames, g1, dim3(256), 0, s, wave, wave_stride, n_eff, live, fe->tb, out,
+                     reinterpret_cast<unsigned int*>(seg_max));
+  GWW_LAUNCH_CHECK();
+  dim3 g2(kNmel, (unsigned)n_seg);
+  hipLaunchKernelGGL(k_logmel_finalize, g2, dim3(256), 0, s, out, live,
+                     reinterpret_cast<const unsigned int*>(seg_max));
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}

@@ -1,0 +1,223 @@
+"""``WhisperEncoder``-compatible module backed by libgww.so.
+
+Mirrors the HuggingFace surface the reference uses:
+
+* built like ``WhisperModel.from_pretrained(id).encoder``
+  (reference ``Signal_vs_Noise/src/train.py:227-228``): here
+  ``WhisperEncoder(WhisperConfig.named("tiny"))`` + ``load_state_dict`` of an HF
+  encoder ``state_dict`` (same key names: ``conv1``, ``conv2``,
+  ``embed_positions``, ``layers.N.self_attn.{k,v,q,out}_proj``,
+  ``layers.N.self_attn_layer_norm``, ``layers.N.fc1/fc2``,
+  ``layers.N.final_layer_norm``, ``layer_norm``);
+* ``named_modules()`` yields the names the reference's ``fnmatch`` target search
+  consumes (``src/train.py:230-237``);
+* ``encoder(mel)`` takes ``[B, 80, 3000]`` fp32 on the GPU and returns an object
+  with ``.last_hidden_state [B, 1500, d]`` (``src/model.py:25-26``);
+  ``encoder.config.d_model`` exists (``src/model.py:11``);
+* ``gradient_checkpointing_enable()`` is accepted (``MLGWSC-1/train.py:662``).
+
+The submodules hold parameters only; all arithmetic runs in the HIP library.
+Calling the module with CPU tensors raises -- there is no CPU fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+
+from . import _lib, synth
+from ._lib import check, lib
+
+
+@dataclass
+class WhisperConfig:
+    d_model: int = 384
+    encoder_layers: int = 4
+    encoder_attention_heads: int = 6
+    encoder_ffn_dim: int = 1536
+    num_mel_bins: int = 80
+    max_source_positions: int = 1500
+    dropout: float = 0.0
+
+    @staticmethod
+    def named(name: str) -> "WhisperConfig":
+        d, L, H, F = synth.ENCODER_SIZES[name]
+        return WhisperConfig(d, L, H, F)
+
+
+@dataclass
+class BaseModelOutput:
+    last_hidden_state: torch.Tensor
+
+    def __getitem__(self, i):
+        return (self.last_hidden_state,)[i]
+
+
+class _Attention(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj = nn.Linear(d, d, bias=False)
+        self.v_proj = nn.Linear(d, d, bias=True)
+        self.q_proj = nn.Linear(d, d, bias=True)
+        self.out_proj = nn.Linear(d, d, bias=True)
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, d, ffn):
+        super().__init__()
+        self.self_attn = _Attention(d)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, ffn)
+        self.fc2 = nn.Linear(ffn, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+
+def _effective_weight(linear) -> torch.Tensor:
+    """Dense fp32 weight a (possibly DoRA-wrapped) projection currently represents."""
+    if hasattr(linear, "effective_weight"):
+        return linear.effective_weight()
+    return linear.weight
+
+
+def _bias(linear):
+    base = getattr(linear, "base_layer", linear)
+    return base.bias
+
+
+class WhisperEncoder(nn.Module):
+    """Parameter container + launcher for the HIP encoder forward."""
+
+    def __init__(self, config: WhisperConfig, precision: str = "bf16"):
+        super().__init__()
+        self.config = config
+        d = config.d_model
+        self.conv1 = nn.Conv1d(config.num_mel_bins, d, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv1d(d, d, kernel_size=3, stride=2, padding=1)
+        self.embed_positions = nn.Embedding(config.max_source_positions, d)
+        self.embed_positions.requires_grad_(False)
+        with torch.no_grad():
+            self.embed_positions.weight.copy_(torch.from_numpy(synth.sinusoid_table(config.max_source_positions, d)))
+        self.layers = nn.ModuleList([_EncoderLayer(d, config.encoder_ffn_dim) for _ in range(config.encoder_layers)])
+        self.layer_norm = nn.LayerNorm(d)
+        self.precision = precision
+        self.gradient_checkpointing = False
+        self._handle = None
+        self._packed_key = None
+        self._ws = None
+
+    # ---- HF surface the reference touches
+    def gradient_checkpointing_enable(self, *a, **k):
+        self.gradient_checkpointing = True   # activations are recomputed-by-design in the HIP backward
+
+    def _freeze_parameters(self):
+        for p in self.parameters():
+            p.requires_grad = False
+
+    @staticmethod
+    def from_numpy_state_dict(sd: dict, config: WhisperConfig, **kw) -> "WhisperEncoder":
+        enc = WhisperEncoder(config, **kw)
+        enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return enc
+
+    # ---- library plumbing
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h is not None:
+            try:
+                lib().gww_encoder_destroy(h)
+            except Exception:
+                pass
+
+    def _ensure_handle(self):
+        if self._handle is None:
+            c = self.config
+            cfg = _lib.EncCfg(c.d_model, c.encoder_layers, c.encoder_attention_heads, c.encoder_ffn_dim,
+                              c.num_mel_bins, 2 * c.max_source_positions)
+            h = C.c_void_p()
+            check(lib().gww_encoder_create(C.byref(cfg), C.byref(h)), "gww_encoder_create")
+            self._handle = h
+        return self._handle
+
+    def _weights_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _sync_weights(self):
+        """Re-pack into the library's bf16/fp32 panels when any parameter changed
+        (optimizer step, load_state_dict, DoRA update)."""
+        key = self._weights_key()
+        if key == self._packed_key:
+            return
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        keep = []   # keep temporaries alive until the async packing kernels are enqueued
+
+        def ptr(t):
+            t = f32(t)
+            keep.append(t)
+            return t.data_ptr()
+
+        g = _lib.EncGlobals(ptr(self.conv1.weight), ptr(self.conv1.bias), ptr(self.conv2.weight),
+                            ptr(self.conv2.bias), ptr(self.embed_positions.weight), ptr(self.layer_norm.weight),
+                            ptr(self.layer_norm.bias))
+        n = len(self.layers)
+        arr = (_lib.EncLayer * n)()
+        for i, L in enumerate(self.layers):
+            a = L.self_attn
+            arr[i] = _lib.EncLayer(
+                ptr(L.self_attn_layer_norm.weight), ptr(L.self_attn_layer_norm.bias),
+                ptr(_effective_weight(a.q_proj)), ptr(_bias(a.q_proj)),
+                ptr(_effective_weight(a.k_proj)),
+                ptr(_effective_weight(a.v_proj)), ptr(_bias(a.v_proj)),
+                ptr(_effective_weight(a.out_proj)), ptr(_bias(a.out_proj)),
+                ptr(L.final_layer_norm.weight), ptr(L.final_layer_norm.bias),
+                ptr(_effective_weight(L.fc1)), ptr(_bias(L.fc1)),
+                ptr(_effective_weight(L.fc2)), ptr(_bias(L.fc2)))
+        check(lib().gww_encoder_set_weights(self._ensure_handle(), C.byref(g), arr, n,
+                                            torch.cuda.current_stream().cuda_stream), "gww_encoder_set_weights")
+        self._packed_key = key
+
+    def _workspace(self, batch: int, prec: int, device) -> torch.Tensor:
+        need = lib().gww_encoder_workspace_bytes(self._ensure_handle(), batch, prec)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = None
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=device)
+        return self._ws
+
+    def forward_raw(self, input_features: torch.Tensor, want_hidden: bool = True, want_last: bool = False):
+        """Launch the HIP forward; returns (last_hidden_state | None, last_token | None)."""
+        x = input_features
+        if not x.is_cuda:
+            raise _lib.GwwError("WhisperEncoder.forward needs GPU tensors: gw_whisper_amd has no CPU fallback "
+                                f"(got input on {x.device})")
+        c = self.config
+        t_in = 2 * c.max_source_positions
+        if x.dim() != 3 or x.shape[1] != c.num_mel_bins or x.shape[-1] != t_in:
+            raise ValueError(f"Whisper expects the mel input features to be of length {t_in}, but found "
+                             f"{x.shape[-1]}. Make sure to pad the input mel features to {t_in}.")
+        if next(self.parameters()).device != x.device:
+            raise _lib.GwwError("encoder parameters and input are on different devices")
+        x = x.to(torch.float32).contiguous()
+        B = x.shape[0]
+        prec = {"bf16": _lib.PREC_BF16, "fp32": _lib.PREC_F32}[self.precision]
+        with torch.cuda.device(x.device):
+            self._sync_weights()
+            ws = self._workspace(B, prec, x.device)
+            hidden = torch.empty((B, c.max_source_positions, c.d_model), dtype=torch.float32,
+                                 device=x.device) if want_hidden else None
+            last = torch.empty((B, c.d_model), dtype=torch.float32, device=x.device) if want_last else None
+            check(lib().gww_encoder_forward(self._handle, x.data_ptr(), B, prec, ws.data_ptr(), ws.numel(),
+                                            hidden.data_ptr() if want_hidden else None,
+                                            last.data_ptr() if want_last else None,
+                                            torch.cuda.current_stream().cuda_stream), "gww_encoder_forward")
+        return hidden, last
+
+    def forward(self, input_features, attention_mask=None, **kwargs):
+        hidden, _ = self.forward_raw(input_features, want_hidden=True, want_last=False)
+        return BaseModelOutput(last_hidden_state=hidden)
+
+    def last_token(self, input_features) -> torch.Tensor:
+        """``self(mel).last_hidden_state[:, -1, :]`` without materialising the other
+        1499 rows of the final LayerNorm (reference ``src/model.py:25-26``)."""
+        return self.forward_raw(input_features, want_hidden=False, want_last=True)[1]

@@ -1,0 +1,133 @@
+"""Tensor-level wrappers around the C ABI (device pointers + the current HIP stream).
+
+PyTorch is used here only for device memory and streams.  Every function
+requires CUDA(HIP) tensors and calls into libgww.so; none has a torch fallback.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, dtype=None, name="tensor") -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.GwwError(f"{name} must live on the GPU (got {t.device}); gw_whisper_amd has no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.GwwError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+_frontend = {}
+
+
+def _fe(device) -> int:
+    idx = torch.device(device).index or 0
+    if idx not in _frontend:
+        import ctypes as C
+        h = C.c_void_p()
+        with torch.cuda.device(idx):
+            check(lib().gww_frontend_create(C.byref(h)), "gww_frontend_create")
+        _frontend[idx] = h
+    return _frontend[idx]
+
+
+def logmel(wave: torch.Tensor, n_samples: int | None = None) -> torch.Tensor:
+    """[n, L] fp32 GPU waveform (16 kHz) -> [n, 80, 3000] fp32 ``input_features``.
+
+    Same arithmetic as ``WhisperFeatureExtractor(...)`` (reference call site
+    Signal_vs_Noise/src/dataset.py:20-21): zero-pad/truncate to 30 s, STFT, mel, log10,
+    per-segment dynamic-range clamp, affine.
+    """
+    if wave.dim() == 1:
+        wave = wave[None]
+    wave = _dev(wave, torch.float32, "wave")
+    n, L = wave.shape
+    n_samples = L if n_samples is None else n_samples
+    out = torch.empty((n, 80, 3000), dtype=torch.float32, device=wave.device)
+    seg_max = torch.empty((max(n, 1),), dtype=torch.float32, device=wave.device)
+    with torch.cuda.device(wave.device):
+        step = 32768   # gridDim.y limit
+        for i in range(0, n, step):
+            m = min(step, n - i)
+            check(lib().gww_logmel_f32(_fe(wave.device), wave[i:].data_ptr(), m, n_samples, wave.stride(0),
+                                       out[i:].data_ptr(), seg_max[i:].data_ptr(), _stream()), "gww_logmel_f32")
+    return out
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out_bf16: bool = False) -> torch.Tensor:
+    x = _dev(x, torch.float32, "x")
+    M, d = x.shape
+    y = torch.empty((M, d), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().gww_layernorm(x.data_ptr(), _dev(w, torch.float32).data_ptr(), _dev(b, torch.float32).data_ptr(),
+                                  y.data_ptr(), int(out_bf16), M, d, _stream()), "gww_layernorm")
+    return y
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    x = _dev(x, torch.float32, "x")
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().gww_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "gww_cast_f32_bf16")
+    return y
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, epilogue: int = 0,
+         resid: torch.Tensor | None = None) -> torch.Tensor:
+    """C = A[M,K] @ W[N,K]^T + bias with epilogue 0 none / 1 GELU / 2 += resid.
+
+    bf16 A/W -> bf16 C (fp32 C for the residual epilogue); fp32 A/W -> fp32 C.
+    """
+    bf = a.dtype == torch.bfloat16
+    a = _dev(a, torch.bfloat16 if bf else torch.float32, "A")
+    w = _dev(w, a.dtype, "W")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise _lib.GwwError(f"gemm: A is [{M},{K}] but W is {tuple(w.shape)}")
+    out_dtype = torch.float32 if (not bf or epilogue == _lib.EPI_RESID) else torch.bfloat16
+    c = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    bptr = _dev(bias, torch.float32, "bias").data_ptr() if bias is not None else None
+    rptr = _dev(resid, torch.float32, "resid").data_ptr() if resid is not None else None
+    fn = lib().gww_gemm_bf16 if bf else lib().gww_gemm_f32
+    with torch.cuda.device(a.device):
+        check(fn(a.data_ptr(), w.data_ptr(), bptr, rptr, c.data_ptr(), M, N, K, epilogue, _stream()), "gww_gemm")
+    return c
+
+
+def attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:
+    """qkv [B, T, 3 d] (q pre-scaled) -> ctx [B, T, d]; bf16 or fp32."""
+    bf = qkv.dtype == torch.bfloat16
+    qkv = _dev(qkv, torch.bfloat16 if bf else torch.float32, "qkv")
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    if d != n_heads * 64:
+        raise _lib.GwwError(f"attention: d={d} != n_heads*64")
+    ctx = torch.empty((B, T, d), dtype=qkv.dtype, device=qkv.device)
+    fn = lib().gww_attention_bf16 if bf else lib().gww_attention_f32
+    with torch.cuda.device(qkv.device):
+        check(fn(qkv.data_ptr(), ctx.data_ptr(), B, T, n_heads, _stream()), "gww_attention")
+    return ctx
+
+
+def dora_merge(w0: torch.Tensor, a: torch.Tensor, b: torch.Tensor, m: torch.Tensor, scaling: float,
+               return_norm: bool = False):
+    """W_eff = (m / ||W0 + s B A||_row) * (W0 + s B A)  (peft 0.12.0 dora.py), fp32."""
+    w0 = _dev(w0, torch.float32, "w0")
+    d_out, d_in = w0.shape
+    r = a.shape[0]
+    out = torch.empty_like(w0)
+    nrm = torch.empty((d_out,), dtype=torch.float32, device=w0.device)
+    with torch.cuda.device(w0.device):
+        check(lib().gww_dora_merge_f32(w0.data_ptr(), _dev(a, torch.float32).data_ptr(),
+                                       _dev(b, torch.float32).data_ptr(), _dev(m, torch.float32).data_ptr(),
+                                       float(scaling), d_out, d_in, r, out.data_ptr(), nrm.data_ptr(), _stream()),
+              "gww_dora_merge_f32")
+    return (out, nrm) if return_norm else out

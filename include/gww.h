@@ -1,0 +1,152 @@
+/*
+ * gww.h -- C ABI of libgww.so, the MI355X (gfx950) hot path of GW-Whisper.
+ *
+ * The reference (chayanchatterjee/GW-Whisper) is pure Python; its hot path is
+ * the object protocol of three third-party classes.
+ * There is therefore no FFI in the reference to mirror symbol-for-symbol; each
+ * entry point below names the reference call it replaces (file:line relative to
+ * the reference tree, "HF:" = the transformers package the reference imports).
+ * The Python shim in gw_whisper_amd/ binds these with ctypes and presents the
+ * reference's own call surface (WhisperFeatureExtractor / WhisperEncoder /
+ * peft get_peft_model); INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless said otherwise
+ *   - every launch is asynchronous on the caller's hipStream_t (passed as void*)
+ *   - return value: 0 = ok, negative = error (gww_last_error() has the text)
+ *   - the library keeps no global mutable state besides the per-thread error
+ *     string; handles are thread-compatible (one handle per thread/stream)
+ *   - plain C types only: no torch, no C++ in the signatures
+ */
+#ifndef GWW_H
+#define GWW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GWW_VERSION 100  /* 0.1.0 */
+
+#define GWW_OK 0
+#define GWW_ERR_ARG (-1)      /* bad argument (shape, null pointer, unsupported size) */
+#define GWW_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define GWW_ERR_WORKSPACE (-3)/* caller's workspace too small */
+#define GWW_ERR_STATE (-4)    /* handle not ready (weights not set) */
+
+/* compute precision of the encoder path */
+#define GWW_PREC_BF16 0  /* bf16 MFMA operands, fp32 accumulate / LN / softmax / residual */
+#define GWW_PREC_F32 1   /* fp32 MFMA (v_mfma_f32_16x16x4_f32): exact fp32, the parity gate */
+
+int gww_version(void);
+const char* gww_last_error(void);
+
+/* --------------------------------------------------------------------------
+ * Front end: log-mel features.
+ * Replaces WhisperFeatureExtractor.__call__ as used at
+ *   Signal_vs_Noise/src/dataset.py:20-21,40 ; Glitch_classification/src/dataset.py:46
+ *   (impl HF:models/whisper/feature_extraction_whisper.py:135-168,193-346).
+ * wave   [n_seg, wave_stride] fp32, the first n_samples of each row are the
+ *        16 kHz samples (zero padded / truncated to 480000 like HF does)
+ * out    [n_seg, 80, 3000] fp32  == input_features
+ * seg_max[n_seg] fp32 scratch (per-segment max of the raw log10 mel)
+ * Exact shortcut: frames that only see zero padding are filled with the one
+ * constant HF would produce; only ceil((n_samples+200)/160) frames run a DFT.
+ * -------------------------------------------------------------------------- */
+typedef struct gww_frontend gww_frontend;
+int gww_frontend_create(gww_frontend** out);          /* uploads window / twiddle / filterbank tables */
+void gww_frontend_destroy(gww_frontend* fe);
+int gww_logmel_f32(gww_frontend* fe, const float* wave, int n_seg, int n_samples,
+                   long wave_stride, float* out, float* seg_max, void* stream);
+
+/* --------------------------------------------------------------------------
+ * Encoder.  Replaces WhisperEncoder.forward as built at
+ *   Signal_vs_Noise/src/train.py:227-228,240 ; Glitch_classification/src/train.py:159 ;
+ *   MLGWSC-1/train.py:660-663 ; MLGWSC-1/inference.py:408-410
+ *   (impl HF:models/whisper/modeling_whisper.py:592-646, layers :379-413,
+ *    attention :284-356 / :215-238).
+ * -------------------------------------------------------------------------- */
+typedef struct {
+  int d_model;   /* 384 / 512 / 768 ... multiple of 64 */
+  int n_layers;
+  int n_heads;   /* d_model / 64 (head_dim is 64 for every Whisper size) */
+  int ffn;       /* 4 * d_model */
+  int n_mels;    /* 80 */
+  int t_in;      /* 3000 mel frames  -> t_in/2 tokens */
+} gww_enc_cfg;
+
+/* fp32 master weights, HF layout ([out,in] linears, [out,in,3] convs). */
+typedef struct {
+  const float* conv1_w; const float* conv1_b;   /* [d,80,3] [d] */
+  const float* conv2_w; const float* conv2_b;   /* [d,d,3]  [d] */
+  const float* pos;                             /* [t_in/2, d] embed_positions.weight */
+  const float* ln_w; const float* ln_b;         /* final layer_norm */
+} gww_enc_globals;
+
+typedef struct {
+  const float* ln1_w; const float* ln1_b;       /* self_attn_layer_norm */
+  const float* q_w; const float* q_b;           /* [d,d] [d]  (DoRA-merged when adapted) */
+  const float* k_w;                             /* [d,d], no bias (HF:modeling_whisper.py:279) */
+  const float* v_w; const float* v_b;
+  const float* o_w; const float* o_b;           /* out_proj */
+  const float* ln2_w; const float* ln2_b;       /* final_layer_norm */
+  const float* fc1_w; const float* fc1_b;       /* [ffn,d] [ffn] */
+  const float* fc2_w; const float* fc2_b;       /* [d,ffn] [d] */
+} gww_enc_layer;
+
+typedef struct gww_encoder gww_encoder;
+
+int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out);
+void gww_encoder_destroy(gww_encoder* enc);
+/* (Re)pack the weights into the library-owned kernel layouts (bf16 [N,K] panels,
+ * q scale folded in, conv taps flattened).  Call again after an optimizer step /
+ * DoRA merge.  Asynchronous on `stream`. */
+int gww_encoder_set_weights(gww_encoder* enc, const gww_enc_globals* g,
+                            const gww_enc_layer* layers, int n_layers, void* stream);
+/* bytes of caller-owned scratch gww_encoder_forward needs for `batch` segments */
+size_t gww_encoder_workspace_bytes(const gww_encoder* enc, int batch, int precision);
+/* mel [batch,80,3000] fp32 (== input_features).  Either output may be NULL:
+ *   last_hidden [batch, 1500, d] fp32 (== .last_hidden_state)
+ *   last_token  [batch, d]       fp32 (== .last_hidden_state[:, -1, :],
+ *                Signal_vs_Noise/src/model.py:25-26) */
+int gww_encoder_forward(gww_encoder* enc, const float* mel, int batch, int precision,
+                        void* workspace, size_t workspace_bytes,
+                        float* last_hidden, float* last_token, void* stream);
+
+/* --------------------------------------------------------------------------
+ * DoRA.  Replaces peft's DoRA Linear (peft 0.12.0 tuners/lora/dora.py) created at
+ *   Signal_vs_Noise/src/train.py:263-264 ; MLGWSC-1/train.py:695-696.
+ *   W' = W0 + s B A ; n = ||W'|| per output row ; W_eff = (m/n)[:,None] W'
+ * w0 [d_out,d_in], a [r,d_in], b [d_out,r], m [d_out]  ->  w_eff [d_out,d_in],
+ * norm_out [d_out] (may be NULL).  All fp32.
+ * -------------------------------------------------------------------------- */
+int gww_dora_merge_f32(const float* w0, const float* a, const float* b, const float* m,
+                       float scaling, int d_out, int d_in, int r,
+                       float* w_eff, float* norm_out, void* stream);
+
+/* --------------------------------------------------------------------------
+ * Kernel-level entry points (used by the parity tests and by the Python
+ * autograd shim; same conventions).
+ * -------------------------------------------------------------------------- */
+/* y[M,d] (bf16 if out_bf16 else fp32) = LayerNorm(x[M,d] fp32) * w + b, eps 1e-5 */
+int gww_layernorm(const float* x, const float* w, const float* b, void* y, int out_bf16,
+                  long M, int d, void* stream);
+/* C[M,N] = A[M,K] @ W[N,K]^T + bias ; epilogue: 0 none, 1 exact GELU, 2 += resid (fp32 out).
+ * bf16 variant: A, W bf16; C bf16 (epilogue 0/1) or fp32 (epilogue 2).
+ * f32 variant : everything fp32. */
+int gww_gemm_bf16(const void* A, const void* W, const float* bias, const float* resid, void* C,
+                  long M, int N, int K, int epilogue, void* stream);
+int gww_gemm_f32(const float* A, const float* W, const float* bias, const float* resid, float* C,
+                 long M, int N, int K, int epilogue, void* stream);
+/* softmax(q k^T) v per head, q pre-scaled; qkv [B,T,3*d] (q|k|v), ctx [B,T,d]; head_dim 64 */
+int gww_attention_bf16(const void* qkv, void* ctx, int B, int T, int n_heads, void* stream);
+int gww_attention_f32(const float* qkv, float* ctx, int B, int T, int n_heads, void* stream);
+/* fp32 -> bf16 (round to nearest even), n elements */
+int gww_cast_f32_bf16(const float* x, void* y, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GWW_H */

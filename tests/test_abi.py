@@ -1,0 +1,93 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every
+symbol include/gww.h declares; argument validation that needs no GPU."""
+
+import os
+import re
+
+import pytest
+
+import gw_whisper_amd
+from gw_whisper_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "gww.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gww_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_present_and_loads():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = gw_whisper_amd.lib()
+    assert lib.gww_version() == 100
+
+
+def test_every_header_symbol_is_exported_and_bound():
+    lib = gw_whisper_amd.lib()
+    syms = _header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in gww.h but not exported by libgww.so"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in _lib.py"
+    for s in _lib.SIGNATURES:
+        assert s in syms, f"{s} bound in _lib.py but not declared in gww.h"
+
+
+def test_argument_errors_without_gpu():
+    import ctypes as C
+    lib = gw_whisper_amd.lib()
+    # NULL handle / pointers are rejected before any HIP call
+    assert lib.gww_logmel_f32(None, None, 1, 16000, 16000, None, None, None) == -1
+    assert b"NULL" in lib.gww_last_error()
+    bad = _lib.EncCfg(100, 4, 6, 1536, 80, 3000)      # d_model not a multiple of 128
+    h = C.c_void_p()
+    assert lib.gww_encoder_create(C.byref(bad), C.byref(h)) == -1
+    assert b"d_model" in lib.gww_last_error()
+    bad = _lib.EncCfg(384, 4, 5, 1536, 80, 3000)      # heads * 64 != d
+    assert lib.gww_encoder_create(C.byref(bad), C.byref(h)) == -1
+    assert lib.gww_gemm_bf16(None, None, None, None, None, 1, 4, 64, 7, None) == -1   # bad epilogue
+
+
+def test_cpu_tensors_are_refused():
+    """No CPU fallback: the product path raises on CPU tensors instead of computing."""
+    import torch
+    from gw_whisper_amd import ops
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    with pytest.raises(gw_whisper_amd.GwwError, match="GPU"):
+        ops.logmel(torch.zeros(1, 16000))
+    enc = WhisperEncoder(WhisperConfig(128, 1, 2, 512))
+    with pytest.raises(gw_whisper_amd.GwwError, match="no CPU fallback"):
+        enc(torch.zeros(1, 80, 3000))
+
+
+def test_encoder_module_surface():
+    """HF names the reference's fnmatch target search consumes
+    (Signal_vs_Noise/src/train.py:230-237) and HF state-dict keys."""
+    import fnmatch
+    from gw_whisper_amd import synth
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    enc = WhisperEncoder(WhisperConfig.named("tiny"))
+    names = [n for n, _ in enc.named_modules()]
+    pats = ["layers.*.self_attn.q_proj", "layers.*.self_attn.k_proj", "layers.*.self_attn.v_proj",
+            "layers.*.self_attn.o_proj"]
+    matched = [n for n in names if any(fnmatch.fnmatch(n, p) for p in pats)]
+    assert len(matched) == 12          # o_proj matches nothing in HF Whisper
+    assert set(enc.state_dict().keys()) == set(synth.named_encoder_state_dict("tiny").keys())
+    assert enc.config.d_model == 384
+    assert not enc.embed_positions.weight.requires_grad
+    with pytest.raises(ValueError, match="3000"):
+        import torch
+        enc.forward_raw(torch.zeros(1, 80, 2999, device="meta") if False else _FakeCuda((1, 80, 2999)))
+
+
+class _FakeCuda:
+    """Shape-only stand-in so the length check is reachable without a GPU."""
+    is_cuda = True
+
+    def __init__(self, shape):
+        self.shape = shape
+
+    def dim(self):
+        return len(self.shape)

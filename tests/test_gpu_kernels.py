@@ -1,0 +1,226 @@
+"""HIP kernels vs the numpy oracle, through the C ABI.  Needs an MI355X (-m gpu)."""
+
+import numpy as np
+import pytest
+
+from gw_whisper_amd import synth
+from oracle import dora as odora
+from oracle import encoder as oenc
+from oracle import logmel as olm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _bf(x):
+    """numpy fp32 -> values rounded to bf16 (as fp32)."""
+    return oenc.bf16_round(np.asarray(x, np.float32))
+
+
+# ------------------------------------------------------------------ log-mel
+def test_logmel_matches_oracle_and_hf_golden(T, gww, golden):
+    from gw_whisper_amd import ops
+    g = golden("logmel.npz")
+    seg = synth.strain_segments(4, seed=11)
+    out = ops.logmel(T.from_numpy(seg).cuda()).cpu().numpy()
+    assert out.shape == (4, 80, 3000)
+    ref = olm.log_mel(seg)
+    # fp32 DFT by direct summation vs an FFT: tolerance 2e-5 on values in [-0.7, 1.4]
+    np.testing.assert_allclose(out, ref, atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out[:, :, :112], g["seg16000_frames0_112"], atol=2e-5, rtol=0)
+    for i in range(4):
+        assert np.all(out[i, :, 102:] == out[i, 0, 2999]), "dead frames must be one constant"
+        assert abs(out[i, 0, 2999] - g["seg16000_pad_value"][i]) < 2e-5
+
+
+@pytest.mark.parametrize("n", [1, 159, 12345, 40000])
+def test_logmel_ragged_lengths(T, gww, golden, n):
+    from gw_whisper_amd import ops
+    g = golden("logmel.npz")
+    w = synth.strain_segments(1, seed=100 + n, n_samples=n)
+    out = ops.logmel(T.from_numpy(w).cuda()).cpu().numpy()[0]
+    ref = g[f"len{n}_frames"]
+    np.testing.assert_allclose(out[:, :ref.shape[1]], ref, atol=2e-5, rtol=0)
+    assert abs(out[0, 2999] - g[f"len{n}_pad_value"]) < 2e-5
+
+
+@pytest.mark.parametrize("n", [480000, 480321])
+def test_logmel_full_buffer_and_truncation(T, gww, golden, n):
+    from gw_whisper_amd import ops
+    g = golden("logmel.npz")
+    w = synth.strain_segments(1, seed=200 + n, n_samples=n)
+    out = ops.logmel(T.from_numpy(w).cuda()).cpu().numpy()[0]
+    np.testing.assert_allclose(out[:, g[f"len{n}_cols"]], g[f"len{n}_frames"], atol=2e-5, rtol=0)
+
+
+def test_logmel_constant_collapse_and_empty(T, gww, golden):
+    from gw_whisper_amd import ops
+    g = golden("logmel.npz")
+    z = ops.logmel(T.zeros(1, 16000).cuda()).cpu().numpy()[0]
+    assert z.min() == z.max() == g["zeros_value"][0] == -1.5
+    r = ops.logmel(T.from_numpy((synth.strain_segments(1, seed=5) * 1e-21).astype(np.float32)).cuda()).cpu().numpy()[0]
+    assert r.min() == g["raw1e21_value"][0] and r.max() == g["raw1e21_value"][1]
+    e = ops.logmel(T.zeros(0, 16000).cuda())
+    assert tuple(e.shape) == (0, 80, 3000)
+
+
+def test_logmel_idempotent_batching(T, gww):
+    """Size-independent property: a segment's features do not depend on its batch."""
+    from gw_whisper_amd import ops
+    seg = synth.strain_segments(37, seed=2)
+    a = ops.logmel(T.from_numpy(seg).cuda()).cpu().numpy()
+    b = ops.logmel(T.from_numpy(seg[5:6]).cuda()).cpu().numpy()
+    assert np.array_equal(a[5], b[0])
+
+
+# ------------------------------------------------------------------ LayerNorm / cast
+@pytest.mark.parametrize("d", [128, 384, 512, 768])
+def test_layernorm(T, gww, d):
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(d)
+    x = (rng.standard_normal((1003, d)) * 3 + 0.5).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    ref = oenc.layer_norm(x.astype(np.float64), w, b)
+    y = ops.layernorm(T.from_numpy(x).cuda(), T.from_numpy(w).cuda(), T.from_numpy(b).cuda()).cpu().numpy()
+    np.testing.assert_allclose(y, ref, atol=3e-6, rtol=1e-5)
+    yb = ops.layernorm(T.from_numpy(x).cuda(), T.from_numpy(w).cuda(), T.from_numpy(b).cuda(), out_bf16=True)
+    # same fp32 value rounded to bf16; the two instantiations may contract the final FMA
+    # differently, which flips a rounding tie in a handful of elements
+    ybf = yb.float().cpu().numpy()
+    np.testing.assert_allclose(ybf, _bf(y), atol=0, rtol=2 ** -7)
+    assert (ybf == _bf(y)).mean() > 0.9999
+
+
+def test_cast_bf16_round_to_nearest_even(T, gww):
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(100003).astype(np.float32) * 10
+    x[:4] = [1.00390625, 1.005859375, -0.0, 3.0e38]
+    y = ops.cast_bf16(T.from_numpy(x).cuda()).float().cpu().numpy()
+    np.testing.assert_array_equal(y, _bf(x))
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 384), (1501, 1152, 384), (777, 384, 1536), (64, 1536, 384)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_bf16(T, gww, M, N, K, epi):
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(M * 7 + N + K + epi)
+    a = _bf(rng.standard_normal((M, K)))
+    w = _bf(rng.standard_normal((N, K)) / np.sqrt(K))
+    bias = rng.standard_normal(N).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    if epi == 1:
+        ref = oenc.gelu(ref)
+    if epi == 2:
+        ref = ref + resid
+    c = ops.gemm(T.from_numpy(a).cuda().bfloat16(), T.from_numpy(w).cuda().bfloat16(), T.from_numpy(bias).cuda(),
+                 epilogue=epi, resid=T.from_numpy(resid).cuda() if epi == 2 else None)
+    got = c.float().cpu().numpy()
+    if epi == 2:
+        # fp32 out: only fp32 accumulation-order noise
+        np.testing.assert_allclose(got, ref, atol=2e-5 * np.sqrt(K), rtol=1e-5)
+    else:
+        # bf16 out: one rounding of the exact result
+        np.testing.assert_allclose(got, ref, atol=1e-5 * np.sqrt(K), rtol=2 ** -8)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (300, 384, 384), (1501, 128, 96)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_f32(T, gww, M, N, K, epi):
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(M + N + K + epi)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    if epi == 1:
+        ref = oenc.gelu(ref)
+    if epi == 2:
+        ref = ref + resid
+    c = ops.gemm(T.from_numpy(a).cuda(), T.from_numpy(w).cuda(), T.from_numpy(bias).cuda(), epilogue=epi,
+                 resid=T.from_numpy(resid).cuda() if epi == 2 else None)
+    np.testing.assert_allclose(c.cpu().numpy(), ref, atol=3e-6 * np.sqrt(K), rtol=1e-5)
+
+
+def test_gemm_identity_with_asymmetric_operand(T, gww):
+    """A = I against an asymmetric W catches a transposed C write (guide section 3)."""
+    from gw_whisper_amd import ops
+    n = 128
+    a = np.eye(n, dtype=np.float32)
+    w = _bf(np.arange(n * n, dtype=np.float32).reshape(n, n) % 251 - 100.0)
+    c = ops.gemm(T.from_numpy(a).cuda().bfloat16(), T.from_numpy(w).cuda().bfloat16()).float().cpu().numpy()
+    np.testing.assert_array_equal(c, w.T)
+
+
+# ------------------------------------------------------------------ attention
+def _attn_ref(qkv, H, bf16):
+    B, Tn, d3 = qkv.shape
+    d = d3 // 3
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    return oenc.attention(q.astype(np.float64), k.astype(np.float64), v.astype(np.float64), H, bf16, np.float64)
+
+
+@pytest.mark.parametrize("B,Tn,H", [(1, 64, 1), (2, 200, 2), (1, 1500, 2), (3, 129, 6)])
+def test_attention_bf16(T, gww, B, Tn, H):
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(B * 1000 + Tn + H)
+    qkv = _bf(rng.standard_normal((B, Tn, 3 * H * 64)) * 0.7)
+    ref = _attn_ref(qkv, H, True)
+    got = ops.attention(T.from_numpy(qkv).cuda().bfloat16(), H).float().cpu().numpy()
+    # bf16 P and bf16 output rounding on |ctx| <~ 1
+    np.testing.assert_allclose(got, ref, atol=6e-3, rtol=2 ** -7)
+
+
+def test_attention_bf16_spike_forces_rescale(T, gww):
+    """One key dominates one query late in the sequence: the running max jumps at a
+    chosen tile and every earlier partial sum must be rescaled (guide rule 26)."""
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(5)
+    H, Tn = 1, 600
+    qkv = (rng.standard_normal((1, Tn, 192)) * 0.3).astype(np.float32)
+    qkv[0, 17, :64] = 2.0             # q row 17
+    qkv[0, 450, 64:128] = 2.0         # k row 450 -> score 256 vs O(1) elsewhere
+    qkv = _bf(qkv)
+    ref = _attn_ref(qkv, H, True)
+    got = ops.attention(T.from_numpy(qkv).cuda().bfloat16(), H).float().cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=6e-3, rtol=2 ** -7)
+    np.testing.assert_allclose(got[0, 17], qkv[0, 450, 128:192], atol=1e-2)   # row 17 == v[450]
+
+
+@pytest.mark.parametrize("B,Tn,H", [(1, 32, 1), (2, 200, 2), (1, 1500, 2)])
+def test_attention_f32(T, gww, B, Tn, H):
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(B * 1000 + Tn + H + 1)
+    qkv = (rng.standard_normal((B, Tn, 3 * H * 64)) * 0.7).astype(np.float32)
+    ref = _attn_ref(qkv, H, False)
+    got = ops.attention(T.from_numpy(qkv).cuda(), H).cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ DoRA merge
+@pytest.mark.parametrize("d_out,d_in,r", [(384, 384, 8), (768, 768, 16), (1536, 384, 8)])
+def test_dora_merge(T, gww, d_out, d_in, r):
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(d_out + r)
+    W0 = (rng.standard_normal((d_out, d_in)) / np.sqrt(d_in)).astype(np.float32)
+    A, B, m = synth.dora_adapter(d_out, d_in, r, W0, seed=3)
+    s = 32.0 / r
+    ref = odora.dora_merge(W0.astype(np.float64), A.astype(np.float64), B.astype(np.float64), m.astype(np.float64), s)
+    refn = odora.dora_weight_norm(W0.astype(np.float64), A.astype(np.float64), B.astype(np.float64), s)
+    got, nrm = ops.dora_merge(*(T.from_numpy(t).cuda() for t in (W0, A, B, m)), s, return_norm=True)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(nrm.cpu().numpy(), refn, rtol=1e-5)
+    # identity at init: B = 0, m = ||W0||
+    A0, B0, m0 = synth.dora_adapter(d_out, d_in, r, W0, seed=3, trained=False)
+    got0 = ops.dora_merge(*(T.from_numpy(t).cuda() for t in (W0, A0, B0, m0)), s)
+    np.testing.assert_allclose(got0.cpu().numpy(), W0, atol=1e-6, rtol=1e-6)
