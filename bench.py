@@ -88,13 +88,26 @@ def kernel_breakdown(enc_name, B, dev):
         rows.append({"kernel": name, "ms": ms, "launches_per_fwd": L, "tflops": flops / ms / 1e9 if flops else None,
                      "gbs": bytes_ / ms / 1e6})
 
-    add("layernorm", lambda: ops.layernorm(x32, lnw, lnb, out_bf16=True), 0, M * d * 6)
-    add("gemm_qkv", lambda: ops.gemm(h, wqkv, bqkv, 0), B * 2 * T_TOK * d * 3 * d, M * d * 2 + M * 3 * d * 2)
-    add("attention", lambda: ops.attention(qkv, H), B * fl["attn"], M * 4 * d * 2)
-    add("gemm_out_resid", lambda: ops.gemm(h, wo, bo, 2, resid=x32), B * 2 * T_TOK * d * d, M * d * 10)
-    add("gemm_fc1_gelu", lambda: ops.gemm(h, w1, b1, 1), B * 2 * T_TOK * d * ffn, M * (d + ffn) * 2)
-    add("gemm_fc2_resid", lambda: ops.gemm(f1, w2, bo, 2, resid=x32), B * 2 * T_TOK * d * ffn, M * (ffn * 2 + d * 8))
-    rows[0]["launches_per_fwd"] = 2 * L + 1
+    astat = d in (384, 512)
+    if astat:
+        # the encoder uses the A-stationary kernels with LayerNorm fused into QKV / fc1
+        add("ln+gemm_qkv", lambda: ops.gemm_astat(x32, wqkv, bqkv, 0, ln_w=lnw, ln_b=lnb),
+            B * 2 * T_TOK * d * 3 * d, M * d * 4 + M * 3 * d * 2)
+        add("attention", lambda: ops.attention(qkv, H), B * fl["attn"], M * 4 * d * 2)
+        add("gemm_out", lambda: ops.gemm_astat(h, wo, bo, 0), B * 2 * T_TOK * d * d, M * d * 4)
+        add("resid+ln+gemm_fc1_gelu", lambda: ops.gemm_astat(x32, w1, b1, 1, ln_w=lnw, ln_b=lnb, delta=h, return_x=True),
+            B * 2 * T_TOK * d * ffn, M * d * 10 + M * ffn * 2)
+    else:
+        add("layernorm", lambda: ops.layernorm(x32, lnw, lnb, out_bf16=True), 0, M * d * 6)
+        rows[-1]["launches_per_fwd"] = 2 * L
+        add("gemm_qkv", lambda: ops.gemm(h, wqkv, bqkv, 0), B * 2 * T_TOK * d * 3 * d, M * d * 2 + M * 3 * d * 2)
+        add("attention", lambda: ops.attention(qkv, H), B * fl["attn"], M * 4 * d * 2)
+        add("gemm_out_resid", lambda: ops.gemm(h, wo, bo, 2, resid=x32), B * 2 * T_TOK * d * d, M * d * 10)
+        add("gemm_fc1_gelu", lambda: ops.gemm(h, w1, b1, 1), B * 2 * T_TOK * d * ffn, M * (d + ffn) * 2)
+    if astat:
+        add("gemm_fc2", lambda: ops.gemm(f1, w2, bo, 0), B * 2 * T_TOK * d * ffn, M * (ffn * 2 + d * 2))
+    else:
+        add("gemm_fc2_resid", lambda: ops.gemm(f1, w2, bo, 2, resid=x32), B * 2 * T_TOK * d * ffn, M * (ffn * 2 + d * 8))
     return rows
 
 

@@ -20,6 +20,7 @@ int fail(int code, const char* fmt, ...) {
 // NV = d / 128 float2 per lane.  Two-pass (mean, then centred variance) in registers.
 template <int NV, bool OUT_BF16>
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, long row_stride,
+                                                   const unsigned short* __restrict__ delta,
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ b, void* __restrict__ y,
                                                    long M) {
@@ -33,6 +34,11 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     v[j] = xr[lane + 64 * j];
+    if (delta) {   // deferred residual add: x + bf16 delta of the last GEMM (same row layout)
+      const unsigned int dv = reinterpret_cast<const unsigned int*>(delta + row * row_stride)[lane + 64 * j];
+      v[j].x += bf2f((unsigned short)(dv & 0xffff));
+      v[j].y += bf2f((unsigned short)(dv >> 16));
+    }
     s += v[j].x + v[j].y;
   }
   const float mean = wave_sum(s) * (1.0f / d);
@@ -60,14 +66,14 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 }
 
 template <bool OUT_BF16>
-static int ln_dispatch(const float* x, long row_stride, const float* w, const float* b, void* y, long M,
-                       int d, hipStream_t s) {
+static int ln_dispatch(const float* x, long row_stride, const unsigned short* delta, const float* w,
+                       const float* b, void* y, long M, int d, hipStream_t s) {
   GWW_REQUIRE(d % 128 == 0 && d >= 128 && d <= 1280, "layernorm: d=%d must be a multiple of 128 <= 1280", d);
   if (M == 0) return GWW_OK;
   dim3 grid((unsigned)cdiv(M, 4)), block(256);
 #define GWW_LN_CASE(NV)                                                                          \
   case NV:                                                                                       \
-    hipLaunchKernelGGL((k_layernorm<NV, OUT_BF16>), grid, block, 0, s, x, row_stride, w, b, y, M); \
+    hipLaunchKernelGGL((k_layernorm<NV, OUT_BF16>), grid, block, 0, s, x, row_stride, delta, w, b, y, M); \
     break;
   switch (d / 128) {
     GWW_LN_CASE(1) GWW_LN_CASE(2) GWW_LN_CASE(3) GWW_LN_CASE(4) GWW_LN_CASE(5)
@@ -79,15 +85,16 @@ static int ln_dispatch(const float* x, long row_stride, const float* w, const fl
 }
 
 int launch_layernorm(const float* x, const float* w, const float* b, void* y, int out_bf16, long M, int d,
-                     hipStream_t s) {
-  return out_bf16 ? ln_dispatch<true>(x, d, w, b, y, M, d, s) : ln_dispatch<false>(x, d, w, b, y, M, d, s);
+                     hipStream_t s, const void* delta) {
+  const unsigned short* dl = (const unsigned short*)delta;
+  return out_bf16 ? ln_dispatch<true>(x, d, dl, w, b, y, M, d, s) : ln_dispatch<false>(x, d, dl, w, b, y, M, d, s);
 }
 
 // fp32 LayerNorm of M rows spaced row_stride apart (the last-token fast path:
 // only row 1499 of every segment is consumed, Signal_vs_Noise/src/model.py:25-26)
 int launch_layernorm_rows(const float* x, long row_stride, const float* w, const float* b, float* y,
-                          long M, int d, hipStream_t s) {
-  return ln_dispatch<false>(x, row_stride, w, b, y, M, d, s);
+                          long M, int d, hipStream_t s, const void* delta) {
+  return ln_dispatch<false>(x, row_stride, (const unsigned short*)delta, w, b, y, M, d, s);
 }
 
 // ---------------------------------------------------------------- casts / packing

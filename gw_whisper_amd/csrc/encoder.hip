@@ -196,7 +196,7 @@ extern "C" int gww_encoder_set_weights(gww_encoder* e, const gww_enc_globals* g,
 
 namespace {
 struct WsLayout {
-  size_t melT, c1, x, h, qkv, ctx, f1, total;
+  size_t melT, c1, x, x2, h, d2, qkv, ctx, f1, total;
 };
 WsLayout ws_layout(const gww_enc_cfg& c, int B, int precision) {
   const size_t es = precision == GWW_PREC_BF16 ? 2 : 4;
@@ -204,13 +204,18 @@ WsLayout ws_layout(const gww_enc_cfg& c, int B, int precision) {
   WsLayout w{};
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+  // row-indexed activations are padded so the large-M GEMM can store whole 256-row panels
+  // unconditionally (rows past B*T are scratch); +512 covers conv2's remapped garbage rows
+  const size_t Mp = ((size_t)B * T + 255) / 256 * 256 + 512;
   w.melT = take(((size_t)B * (Tin + 2) * C + kConv1Kpad) * es);
-  w.c1 = take(((size_t)B * (Tin + 2) + 2) * d * es);
-  w.x = take((size_t)B * T * d * 4);
-  w.h = take((size_t)B * T * d * es);
-  w.qkv = take((size_t)B * T * 3 * d * es);
-  w.ctx = take((size_t)B * T * d * es);
-  w.f1 = take((size_t)B * T * F * es);
+  w.c1 = take((((size_t)B * (Tin + 2) + 255) / 256 * 256 + 2) * d * es);
+  w.x = take(Mp * d * 4);
+  w.x2 = take(Mp * d * 4);      // ping-pong partner of x for the fused residual-add prologue
+  w.h = take(Mp * d * es);      // LayerNorm output, or out_proj delta on the A-stationary path
+  w.d2 = take(Mp * d * es);     // fc2 delta on the A-stationary path
+  w.qkv = take(Mp * 3 * d * es);
+  w.ctx = take(Mp * d * es);
+  w.f1 = take(Mp * F * es);
   w.total = off;
   return w;
 }
@@ -256,7 +261,7 @@ extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, 
   auto gemm = [&](const void* A, long lda, const void* W16, const float* W32, const float* bias,
                   const float* resid, const float* pos, void* Cout, long Mr, int N, int K, int epi,
                   int rpb) -> int {
-    return bf ? launch_gemm_bf16(A, lda, W16, bias, resid, pos, Cout, Mr, N, K, epi, rpb, s)
+    return bf ? launch_gemm_bf16(A, lda, W16, bias, resid, pos, Cout, Mr, N, K, epi, rpb, s, /*rows_padded_256=*/1)
               : launch_gemm_f32((const float*)A, lda, W32, bias, resid, pos, (float*)Cout, Mr, N, K, epi, rpb, s);
   };
 
@@ -264,26 +269,54 @@ extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, 
   GWW_TRY(launch_mel_to_tokens(mel, melT, bf ? 1 : 0, B, C, Tin, s));
   GWW_HIP(hipMemsetAsync((char*)melT + (size_t)B * (Tin + 2) * C * es, 0, kConv1Kpad * es, s));
   GWW_HIP(hipMemsetAsync(c1, 0, (size_t)d * es, s));   // zero row 0 of batch 0 (token -1)
-  GWW_TRY(gemm(melT, C, e->c1w, e->c1w32, e->c1b, nullptr, nullptr, c1, (long)B * (Tin + 2), d, kConv1Kpad,
-               EPI_CONV1, Tin + 2));
+  // A-stationary kernels (A panel in registers, fused residual-add + LayerNorm prologue) for K = d <= 512
+  const bool astat = bf && (d == 384 || d == 512) && F % 128 == 0;
+  if (bf && d % 128 == 0)
+    GWW_TRY(launch_gemm_astat(melT, C, nullptr, nullptr, nullptr, nullptr, e->c1w, e->c1b, c1,
+                              (long)B * (Tin + 2), d, kConv1Kpad, EPI_CONV1, Tin + 2, s));
+  else
+    GWW_TRY(gemm(melT, C, e->c1w, e->c1w32, e->c1b, nullptr, nullptr, c1, (long)B * (Tin + 2), d, kConv1Kpad,
+                 EPI_CONV1, Tin + 2));
   GWW_TRY(gemm(c1, 2L * d, e->c2w, e->c2w32, e->c2b, nullptr, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2,
                T + 1));
-  // ---- layers
-  for (int i = 0; i < e->cfg.n_layers; ++i) {
-    const LayerW& L = e->layers[i];
-    GWW_TRY(launch_layernorm(x, L.ln1w, L.ln1b, h, bf ? 1 : 0, M, d, s));
-    GWW_TRY(gemm(h, d, L.wqkv, L.wqkv32, L.bqkv, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0));
-    if (bf) GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s));
-    else GWW_TRY(launch_attention_f32((const float*)qkv, (float*)ctx, B, T, H, s));
-    GWW_TRY(gemm(ctx, d, L.wo, L.wo32, L.bo, x, nullptr, x, M, d, d, EPI_RESID, 0));
-    GWW_TRY(launch_layernorm(x, L.ln2w, L.ln2b, h, bf ? 1 : 0, M, d, s));
-    GWW_TRY(gemm(h, d, L.w1, L.w132, L.b1, nullptr, nullptr, f1, M, F, d, EPI_GELU, 0));
-    GWW_TRY(gemm(f1, F, L.w2, L.w232, L.b2, x, nullptr, x, M, d, F, EPI_RESID, 0));
+  float* xc = x;                       // current residual stream
+  const void* pending = nullptr;       // bf16 delta not yet added to xc (A-stationary path)
+  if (astat) {
+    // Deferred residual: out_proj / fc2 emit a bf16 delta; the NEXT LayerNorm prologue does
+    // x_new = x + delta (written to the ping-pong buffer), LN(x_new) -> GEMM operand.
+    float* xn = (float*)(base + w.x2);
+    void* d1 = h;
+    void* d2 = base + w.d2;
+    for (int i = 0; i < e->cfg.n_layers; ++i) {
+      const LayerW& L = e->layers[i];
+      GWW_TRY(launch_gemm_astat(xc, d, pending, pending ? xn : nullptr, L.ln1w, L.ln1b, L.wqkv, L.bqkv, qkv, M,
+                                3 * d, d, EPI_BIAS, 0, s));
+      if (pending) { float* t = xc; xc = xn; xn = t; }
+      GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s));
+      GWW_TRY(launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, L.wo, L.bo, d1, M, d, d, EPI_BIAS, 0, s));
+      GWW_TRY(launch_gemm_astat(xc, d, d1, xn, L.ln2w, L.ln2b, L.w1, L.b1, f1, M, F, d, EPI_GELU, 0, s));
+      { float* t = xc; xc = xn; xn = t; }
+      GWW_TRY(launch_gemm_bf16(f1, F, L.w2, L.b2, nullptr, nullptr, d2, M, d, F, EPI_BIAS, 0, s, 1));
+      pending = d2;
+    }
+  } else {
+    for (int i = 0; i < e->cfg.n_layers; ++i) {
+      const LayerW& L = e->layers[i];
+      GWW_TRY(launch_layernorm(x, L.ln1w, L.ln1b, h, bf ? 1 : 0, M, d, s));
+      GWW_TRY(gemm(h, d, L.wqkv, L.wqkv32, L.bqkv, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0));
+      if (bf) GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s));
+      else GWW_TRY(launch_attention_f32((const float*)qkv, (float*)ctx, B, T, H, s));
+      GWW_TRY(gemm(ctx, d, L.wo, L.wo32, L.bo, x, nullptr, x, M, d, d, EPI_RESID, 0));
+      GWW_TRY(launch_layernorm(x, L.ln2w, L.ln2b, h, bf ? 1 : 0, M, d, s));
+      GWW_TRY(gemm(h, d, L.w1, L.w132, L.b1, nullptr, nullptr, f1, M, F, d, EPI_GELU, 0));
+      GWW_TRY(gemm(f1, F, L.w2, L.w232, L.b2, x, nullptr, x, M, d, F, EPI_RESID, 0));
+    }
   }
-  // ---- final LayerNorm (HF:modeling_whisper.py:642); callers pool token T-1
-  // (Signal_vs_Noise/src/model.py:25-26), so that row alone is a separate fast output
-  if (last_hidden) GWW_TRY(launch_layernorm(x, e->lnw, e->lnb, last_hidden, 0, M, d, s));
+  // ---- final LayerNorm (HF:modeling_whisper.py:642), with the last pending delta folded in;
+  // callers pool token T-1 (Signal_vs_Noise/src/model.py:25-26): that row alone is a fast output
+  if (last_hidden) GWW_TRY(launch_layernorm(xc, e->lnw, e->lnb, last_hidden, 0, M, d, s, pending));
   if (last_token)
-    GWW_TRY(launch_layernorm_rows(x + (long)(T - 1) * d, (long)T * d, e->lnw, e->lnb, last_token, B, d, s));
+    GWW_TRY(launch_layernorm_rows(xc + (long)(T - 1) * d, (long)T * d, e->lnw, e->lnb, last_token, B, d, s,
+                                  pending ? (const char*)pending + (size_t)(T - 1) * d * 2 : nullptr));
   return GWW_OK;
 }

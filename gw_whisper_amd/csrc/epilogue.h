@@ -14,6 +14,7 @@ __device__ __forceinline__ void epilogue_store4(f32x4 acc, long m, int n, long M
                                                 const float* __restrict__ pos, void* C,
                                                 int rows_per_batch, int valid_rows) {
   if (m >= M || n >= N) return;
+  auto gelu_erf = [](float v) { return BF16OUT ? ::gww::gelu_fast(v) : ::gww::gelu_erf(v); };
   float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
   float v0 = acc[0] + bv.x, v1 = acc[1] + bv.y, v2 = acc[2] + bv.z, v3 = acc[3] + bv.w;
   if constexpr (EPI == EPI_BIAS || EPI == EPI_GELU) {

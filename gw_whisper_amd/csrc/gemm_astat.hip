@@ -1,0 +1,370 @@
+// "A-stationary" bf16 MFMA GEMM for the K <= 512 contractions of the encoder
+// (QKV, fc1, out_proj at whisper-tiny/base; conv1):   C[M,N] = epi(f(A)[M,K] @ W[N,K]^T + b)
+//
+// Why a second GEMM: at d = 384 these GEMMs have 77..307 FLOP per HBM byte, i.e. they
+// sit at or below the gfx950 ridge (~400 FLOP/B).  A tile kernel that streams A tiles
+// per N tile re-reads the A panel N/128 times; with 32 workgroups per XCD the reuse
+// distance (9 MB) exceeds the 4 MB L2, so those re-reads go to Infinity Cache / HBM
+// and set the speed.  Here the A panel never leaves the CU:
+//
+//   * one workgroup = 256 rows = 8 waves x 32 rows.  Each wave keeps ITS 32 rows of A
+//     for the WHOLE K in registers as MFMA operand fragments (K/16 x 4 VGPRs = 96 at
+//     K = 384), read from HBM once, in whole 128-byte lines (8 lanes per row), and
+//     transposed into fragment order through a small wave-private LDS slice.
+//   * fused prologue (AMODE_LN): A = LayerNorm(x [+ delta]) built from the fp32 residual
+//     stream; the deferred residual add x += delta (the bf16 output of the previous
+//     out_proj / fc2 GEMM) is folded in and x is written back once.  The LayerNorm
+//     kernel, its bf16 round trip and the residual read-modify-write of the GEMM
+//     epilogues all disappear; HBM traffic is unchanged.
+//   * only W moves through shared LDS: [128 n][64 k] tiles, global_load_lds (16 B/lane)
+//     into a 7-deep ring (a whole n-tile ahead, so epilogue stores never block the ring), counted vmcnt + one raw s_barrier per k-tile; W stays L2
+//     resident (<= 1.2 MB) and costs 16 KB per 1024 MFMA cycles per CU.
+//   * v_mfma_f32_32x32x16_bf16 with swapped operands (D = W_tile . A_frag^T): the row m
+//     sits on the lane.  The epilogue transposes each 32 x 64 output block through the
+//     wave-private LDS slice so every global store instruction writes whole 128-byte
+//     lines (8 line requests per instruction instead of 32: the scattered 16-byte
+//     pieces of the accumulator layout were request-rate bound, profiles/r01_pmc_*).
+//   * the (n-tile, k-tile) space is flattened: the ring never drains inside a block and
+//     the stores of n-tile t overlap the loads / MFMAs of t+1.
+#include "common.h"
+#include "epilogue.h"
+
+#include <stdlib.h>
+
+namespace gww {
+
+constexpr int AS_WAVES = 8;                      // waves per workgroup (32 rows each); 1 workgroup per CU
+constexpr int AS_THREADS = AS_WAVES * 64;
+constexpr int AS_BM = AS_WAVES * 32, AS_BN = 128, AS_BK = 64;
+constexpr int AS_NST = 7;                       // W ring depth: a whole n-tile (6 k-tiles at K=384) in flight
+constexpr int AS_D = AS_NST - 1;                // k-tiles in flight
+constexpr int AS_W_BYTES = AS_BN * AS_BK * 2;   // 16 KB
+constexpr int AS_GLDS = 16 / AS_WAVES;          // LDS-DMA pieces per thread per k-tile
+constexpr int AS_STORES = 8;                    // 16-byte global stores per thread per n-tile
+constexpr int AS_SLICE_STRIDE = 144;            // bytes per row of the wave-private [32][64] bf16 slice (+16 pad)
+constexpr int AS_SLICE_BYTES = 32 * AS_SLICE_STRIDE;
+
+__device__ __forceinline__ int as_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int N>
+__device__ __forceinline__ void as_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+enum : int { AMODE_BF16 = 0, AMODE_LN = 1 };
+
+// KT = K / 64 (k-tiles); A fragments: af[4 S + j] holds k = 64 S + 32 hh + 8 j .. +7 of row m.
+template <int EPI, int AMODE, int KT>
+__global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __restrict__ Aany, long lda,
+                                                       const unsigned short* __restrict__ delta,
+                                                       float* __restrict__ x_out,
+                                                       const float* __restrict__ ln_w,
+                                                       const float* __restrict__ ln_b,
+                                                       const unsigned short* __restrict__ W,
+                                                       const float* __restrict__ bias, unsigned short* __restrict__ C,
+                                                       long M, int N, int tiles_n, int n_split,
+                                                       int rows_per_batch, int valid_rows, long c_panel_rows,
+                                                       int dbg) {
+  constexpr int K = KT * 64;
+  constexpr int OFF_BIAS = AS_NST * AS_W_BYTES;
+  constexpr int OFF_LN = 0;                       // LayerNorm params live in the (not yet used) ring during the prologue
+  constexpr int OFF_SLICE = OFF_BIAS + 1536 * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[OFF_SLICE + AS_WAVES * AS_SLICE_BYTES];
+  float* lds_bias = reinterpret_cast<float*>(lds + OFF_BIAS);
+  float* lds_lnw = reinterpret_cast<float*>(lds + OFF_LN);
+  float* lds_lnb = lds_lnw + K;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* g_ptr;
+
+  const int panel = blockIdx.x / n_split, split = blockIdx.x - panel * n_split;
+  const int nt0 = (int)((long)split * tiles_n / n_split), nt1 = (int)((long)(split + 1) * tiles_n / n_split);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const long m_base = (long)panel * AS_BM + wave * 32;   // first row of this wave
+  const int total = (nt1 - nt0) * KT;
+  unsigned char* slice = lds + OFF_SLICE + wave * AS_SLICE_BYTES;   // wave-private transpose buffer
+  // coalesced row/chunk roles: one instruction covers 8 rows x 128 B
+  const int crow = lane >> 3, cchunk = lane & 7;
+
+  // ---- W ring: per-lane source offsets of the two 1-KiB pieces this wave stages per k-tile
+  long w_off[AS_GLDS];
+#pragma unroll
+  for (int j = 0; j < AS_GLDS; ++j) {
+    const int row = 8 * (AS_GLDS * wave + j) + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    w_off[j] = (long)row * K + chunk * 8;
+  }
+  auto issue = [&](int it) {
+    const int stage = it % AS_NST;
+    const int nn = nt0 + it / KT, k0 = (it % KT) * AS_BK;
+    unsigned char* sw = lds + stage * AS_W_BYTES + (AS_GLDS * wave) * 1024;
+    const unsigned short* wb = W + (long)nn * AS_BN * K + k0;
+#pragma unroll
+    for (int j = 0; j < AS_GLDS; ++j)
+      __builtin_amdgcn_global_load_lds((g_ptr)(wb + w_off[j]), (lds_ptr)(sw + j * 1024), 16, 0, 0);
+  };
+
+  for (int i = tid; i < (nt1 - nt0) * AS_BN; i += AS_THREADS) lds_bias[i] = bias ? bias[nt0 * AS_BN + i] : 0.f;
+
+  // ---- A fragments (whole K) for this wave's 32 rows
+  bf16x8 af[KT * 4];
+  long grow[4];   // clamped global rows this lane touches in the coalesced passes
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long g = m_base + 8 * i + crow;
+    grow[i] = g < M ? g : M - 1;
+  }
+  if (dbg & 4) {   // tuning aid: no A loads
+#pragma unroll
+    for (int q = 0; q < KT * 4; ++q) af[q] = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+  } else if constexpr (AMODE == AMODE_BF16) {
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(Aany);
+#pragma unroll
+    for (int S = 0; S < KT; ++S) {
+      u32x4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const u32x4*>(A + grow[i] * lda + 64 * S + 8 * cchunk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<u32x4*>(slice + (8 * i + crow) * AS_SLICE_STRIDE + cchunk * 16) = v[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32x4 u = *reinterpret_cast<const u32x4*>(slice + r * AS_SLICE_STRIDE + (4 * hh + j) * 16);
+        asm volatile("" : "+v"(u)::"memory");   // materialise before the slice is overwritten
+        af[4 * S + j] = __builtin_bit_cast(bf16x8, u);
+      }
+    }
+  } else {
+    // x_new = x (+ delta); LayerNorm (HF:modeling_whisper.py:392,402; eps 1e-5) -> bf16 fragments.
+    // Lane (crow, cchunk) owns float4 #cchunk of a 32-float half slice of rows 8 i + crow.
+    const float* X = reinterpret_cast<const float*>(Aany);
+    for (int i = tid; i < K; i += AS_THREADS) {
+      lds_lnw[i] = ln_w[i];
+      lds_lnb[i] = ln_b[i];
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool write_back = (x_out != nullptr) && split == 0;
+    auto load4 = [&](int i, int hs) -> float4 {
+      const long off = grow[i] * lda + 32 * hs + 4 * cchunk;
+      float4 v = *reinterpret_cast<const float4*>(X + off);
+      if (delta) {
+        const u32x2 dv = *reinterpret_cast<const u32x2*>(delta + off);
+        v.x += bf2f((unsigned short)(dv[0] & 0xffff));
+        v.y += bf2f((unsigned short)(dv[0] >> 16));
+        v.z += bf2f((unsigned short)(dv[1] & 0xffff));
+        v.w += bf2f((unsigned short)(dv[1] >> 16));
+      }
+      return v;
+    };
+#pragma unroll 2
+    for (int hs = 0; hs < 2 * KT; ++hs) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = load4(i, hs);
+        if (write_back && m_base + 8 * i + crow < M)
+          *reinterpret_cast<float4*>(x_out + grow[i] * lda + 32 * hs + 4 * cchunk) = v;
+        s1[i] += (v.x + v.y) + (v.z + v.w);
+        s2[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    }
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = s1[i], b = s2[i];
+      a += __shfl_xor(a, 1, 64); b += __shfl_xor(b, 1, 64);
+      a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64);
+      a += __shfl_xor(a, 4, 64); b += __shfl_xor(b, 4, 64);
+      mean[i] = a * (1.0f / K);
+      const float var = fmaxf(b * (1.0f / K) - mean[i] * mean[i], 0.f);
+      rstd[i] = rsqrtf(var + 1e-5f);
+    }
+    asm volatile("" ::: "memory");   // second pass re-reads the rows (L2 hot) instead of holding 192 floats
+    __syncthreads();                 // LN params staged (no LDS-DMA in flight yet)
+#pragma unroll
+    for (int hs = 0; hs < 2 * KT; ++hs) {
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 g = *reinterpret_cast<const float4*>(lds_lnw + 32 * hs + 4 * cchunk);
+      const float4 bb = *reinterpret_cast<const float4*>(lds_lnb + 32 * hs + 4 * cchunk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = load4(i, hs);
+        u32x2 o = {pack2bf((v.x - mean[i]) * rstd[i] * g.x + bb.x, (v.y - mean[i]) * rstd[i] * g.y + bb.y),
+                   pack2bf((v.z - mean[i]) * rstd[i] * g.z + bb.z, (v.w - mean[i]) * rstd[i] * g.w + bb.w)};
+        *reinterpret_cast<u32x2*>(slice + (8 * i + crow) * AS_SLICE_STRIDE + (hs & 1) * 64 + cchunk * 8) = o;
+      }
+      if (hs & 1) {
+        const int S = hs >> 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          u32x4 u = *reinterpret_cast<const u32x4*>(slice + r * AS_SLICE_STRIDE + (4 * hh + j) * 16);
+          asm volatile("" : "+v"(u)::"memory");
+          af[4 * S + j] = __builtin_bit_cast(bf16x8, u);
+        }
+      }
+    }
+  }
+  // every ordinary load / store above is retired before the LDS-DMA ring starts counting
+  as_wait_vmcnt<0>();
+  if constexpr (AMODE == AMODE_LN) __syncthreads();   // LN params (aliased onto the ring) no longer needed
+#pragma unroll
+  for (int p = 0; p < AS_D; ++p)
+    if (p < total) issue(p);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+  const int ntiles = nt1 - nt0;
+  for (int nti = 0; nti < ntiles; ++nti) {
+#pragma unroll
+    for (int S = 0; S < KT; ++S) {
+      const int it = nti * KT + S;
+      // retire this wave's pieces of tile `it`; tiles it+1 .. it+D-1 may stay in flight.  The
+      // epilogue stores of the previous n-tile sit between them and the newest group at S == 0.
+      if (it + AS_D <= total) {
+        // D >= KT: every k-tile of the NEXT n-tile is already in flight when an epilogue issues its
+        // stores, so those stores may stay outstanding for a whole n-tile (any smaller count is
+        // merely conservative: vmcnt retires in order)
+        if (nti > 0) as_wait_vmcnt<AS_GLDS * (AS_D - 1) + AS_STORES>();
+        else as_wait_vmcnt<AS_GLDS * (AS_D - 1)>();
+      } else {
+        as_wait_vmcnt<0>();   // tail: fewer groups in flight than the constant assumes
+      }
+      __builtin_amdgcn_s_barrier();
+      if (it + AS_D < total) issue(it + AS_D);
+      const unsigned char* Ws = lds + (it % AS_NST) * AS_W_BYTES;
+      if (dbg & 2) continue;   // tuning aid: ring only
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x8 wf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(Ws + as_swz(32 * t + r, 4 * hh + j));
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t], af[4 * S + j], acc[t], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: bias (+GELU) -> bf16 -> wave-private LDS transpose -> whole-line stores
+    const int nn = nt0 + nti;
+    if (dbg & 1) {   // tuning aid: no epilogue (keep the accumulators alive)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(acc[t]));
+      if (dbg & 8) continue;
+    }
+    if (!(dbg & 1))
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * half + tt;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int nl = 32 * t + 8 * c + 4 * hh;
+          const float4 bv = *reinterpret_cast<const float4*>(lds_bias + nti * AS_BN + nl);
+          float v0 = acc[t][4 * c] + bv.x, v1 = acc[t][4 * c + 1] + bv.y, v2 = acc[t][4 * c + 2] + bv.z,
+                v3 = acc[t][4 * c + 3] + bv.w;
+          if constexpr (EPI == EPI_GELU || EPI == EPI_CONV1) {
+            v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3);
+          }
+          u32x2 o = {pack2bf(v0, v1), pack2bf(v2, v3)};
+          *reinterpret_cast<u32x2*>(slice + r * AS_SLICE_STRIDE + (32 * tt + 8 * c + 4 * hh) * 2) = o;
+          acc[t][4 * c] = 0.f; acc[t][4 * c + 1] = 0.f; acc[t][4 * c + 2] = 0.f; acc[t][4 * c + 3] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u32x4 u = *reinterpret_cast<const u32x4*>(slice + (8 * i + crow) * AS_SLICE_STRIDE + cchunk * 16);
+        long orow = m_base + 8 * i + crow;
+        if constexpr (EPI == EPI_CONV1) {
+          // rows m = b * rows_per_batch + t -> padded token-major row m + 1; t >= valid is a zero-pad row
+          const int t = (int)(orow % rows_per_batch);
+          if (t >= valid_rows) u = u32x4{0u, 0u, 0u, 0u};
+          orow += 1;
+        }
+        // row-major [M][N], or panel-major [N/64][c_panel_rows][64]: there every store instruction
+        // writes 1 KiB of contiguous memory and the consumer reads whole [rows][64] tiles
+        unsigned short* dst = c_panel_rows ? C + ((long)(2 * nn + half) * c_panel_rows + orow) * 64 + 8 * cchunk
+                                           : C + orow * N + nn * AS_BN + 64 * half + 8 * cchunk;
+        *reinterpret_cast<u32x4*>(dst) = u;
+      }
+    }
+  }
+}
+
+static int as_pick_split(long panels, int tiles_n) {
+  int s = 1;
+  while (panels * s < 768 && s * 2 <= tiles_n && tiles_n % (s * 2) == 0) s *= 2;
+  if (panels * s < 512 && tiles_n % 3 == 0 && s * 3 <= tiles_n) s *= 3;
+  return s;
+}
+
+// bf16 A [M, lda]                                     (ln_w == nullptr), or
+// fp32 residual stream x [M, lda] (+ bf16 delta [M, lda], x_out written back) with fused LayerNorm.
+// C is bf16 [>= roundup(M,256) (+1 for conv1), N]: whole 256-row panels are stored unconditionally.
+int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, const float* ln_w,
+                      const float* ln_b, const void* W, const float* bias, void* C, long M, int N, int K,
+                      int epi, int rows_per_batch, hipStream_t s, long c_panel_rows) {
+  GWW_REQUIRE(A && W && C, "gemm_astat: NULL operand");
+  GWW_REQUIRE(K == 256 || K == 384 || K == 512, "gemm_astat: K=%d unsupported", K);
+  GWW_REQUIRE(N % AS_BN == 0 && N > 0, "gemm_astat: N=%d must be a multiple of 128", N);
+  GWW_REQUIRE(lda % 8 == 0, "gemm_astat: lda must be a multiple of 8");
+  GWW_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (((uintptr_t)C) & 15) == 0,
+              "gemm_astat: operands must be 16-byte aligned");
+  if (M == 0) return GWW_OK;
+  const long panels = cdiv(M, AS_BM);
+  const int tiles_n = N / AS_BN;
+  int n_split = as_pick_split(panels, tiles_n);
+  while (tiles_n / n_split > 12) n_split *= 2;   // lds_bias holds 1536 columns
+  int valid_rows = 0;
+  if (epi == EPI_CONV1) {
+    GWW_REQUIRE(rows_per_batch > 2, "gemm_astat: conv1 epilogue needs rows_per_batch");
+    valid_rows = rows_per_batch - 2;
+  } else {
+    rows_per_batch = 1;
+  }
+  static const int dbg = getenv("GWW_ASTAT_DBG") ? atoi(getenv("GWW_ASTAT_DBG")) : 0;   // tuning aid
+  const bool ln = ln_w != nullptr;
+  GWW_REQUIRE(ln || (!delta && !x_out), "gemm_astat: delta / x_out need the LayerNorm prologue");
+  GWW_REQUIRE(!ln || lda == K, "gemm_astat: fused LayerNorm needs lda == K");
+  dim3 grid((unsigned)(panels * n_split)), block(AS_THREADS);
+#define GWW_AS_LAUNCH(E, AM, KT)                                                                          \
+  hipLaunchKernelGGL((k_gemm_astat<E, AM, KT>), grid, block, 0, s, A, lda, (const unsigned short*)delta,  \
+                     x_out, ln_w, ln_b, (const unsigned short*)W, bias, (unsigned short*)C, M, N, tiles_n, \
+                     n_split, rows_per_batch, valid_rows, c_panel_rows, dbg)
+#define GWW_AS_K(E, AM)                         \
+  do {                                          \
+    if (K == 384) GWW_AS_LAUNCH(E, AM, 6);      \
+    else if (K == 512) GWW_AS_LAUNCH(E, AM, 8); \
+    else GWW_AS_LAUNCH(E, AM, 4);               \
+  } while (0)
+  if (ln) {
+    if (epi == EPI_BIAS) GWW_AS_K(EPI_BIAS, AMODE_LN);
+    else if (epi == EPI_GELU) GWW_AS_K(EPI_GELU, AMODE_LN);
+    else return fail(GWW_ERR_ARG, "gemm_astat: LN-fused variant supports bias / GELU epilogues only");
+  } else {
+    if (epi == EPI_BIAS) GWW_AS_K(EPI_BIAS, AMODE_BF16);
+    else if (epi == EPI_GELU) GWW_AS_K(EPI_GELU, AMODE_BF16);
+    else if (epi == EPI_CONV1) GWW_AS_K(EPI_CONV1, AMODE_BF16);
+    else return fail(GWW_ERR_ARG, "gemm_astat: unsupported epilogue %d", epi);
+  }
+#undef GWW_AS_K
+#undef GWW_AS_LAUNCH
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+}  // namespace gww
+
+using namespace gww;
+
+extern "C" int gww_gemm_astat_bf16(const void* A, const void* delta, float* x_out, const float* ln_w,
+                                   const float* ln_b, const void* W, const float* bias, void* C, long M, int N,
+                                   int K, int epilogue, void* stream) {
+  GWW_REQUIRE(epilogue == 0 || epilogue == 1, "gww_gemm_astat_bf16: epilogue must be 0 (bias) or 1 (GELU)");
+  GWW_REQUIRE((ln_w == nullptr) == (ln_b == nullptr), "gww_gemm_astat_bf16: ln_w and ln_b go together");
+  static const long dbg_panel = getenv("GWW_ASTAT_PANEL") ? atol(getenv("GWW_ASTAT_PANEL")) : 0;   // tuning aid
+  return launch_gemm_astat(A, K, delta, x_out, ln_w, ln_b, W, bias, C, M, N, K, epilogue, 0, (hipStream_t)stream,
+                           dbg_panel ? (M + 255) / 256 * 256 : 0);
+}

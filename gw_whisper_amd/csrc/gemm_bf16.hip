@@ -137,9 +137,155 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const unsigned short* __re
   }
 }
 
+// =====================================================================================
+// v2: persistent row-panel kernel for large M.
+//   * 256 x 128 x 64 tiles, 512 threads = 4 x 2 waves of 64 x 64 (2 waves per SIMD).
+//   * one workgroup owns a 256-row panel and walks a contiguous range of N tiles; the
+//     (n, k) iteration space is flattened so the global->LDS pipeline never drains
+//     inside the panel and the epilogue stores of tile n overlap the loads of tile n+1.
+//   * operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 16 B per lane) into a
+//     3-stage ring, two k-tiles in flight; the ring is retired with COUNTED
+//     s_waitcnt vmcnt(N) + a raw s_barrier (one per k-tile), never vmcnt(0) in the loop.
+//     The LDS image is lane-linear, so the XOR swizzle is applied to the per-lane
+//     SOURCE chunk and undone on the ds_read_b128 side (same involution).
+//   * bias is staged in LDS once, so the in-loop epilogue issues no VGPR-destination
+//     loads (those would force vmcnt(0) and drain the ring); stores are unconditional
+//     (the caller pads every activation buffer to a multiple of 256 rows), which keeps
+//     the per-wave VMEM count exact for the counted waits.
+constexpr int BM2 = 256, BN2 = 128, BK2 = 64, NSTAGE = 3;
+constexpr int A2_BYTES = BM2 * BK2 * 2, W2_BYTES = BN2 * BK2 * 2, STAGE2_BYTES = A2_BYTES + W2_BYTES;
+constexpr int GLDS_PER_TILE = 6;     // per thread: 4 (A) + 2 (W)
+constexpr int STORES_PER_TILE = 16;  // per thread: 4 x 4 accumulator tiles, one vector store each
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void k_gemm_bf16_v2(const unsigned short* __restrict__ A, long lda,
+                                                         const unsigned short* __restrict__ W,
+                                                         const float* __restrict__ bias, const float* resid,
+                                                         const float* __restrict__ pos, void* C, long M, int N,
+                                                         int K, int rows_per_batch, int valid_rows, int tiles_n,
+                                                         int n_split) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE2_BYTES + 1536 * 4];
+  float* lds_bias = reinterpret_cast<float*>(lds + NSTAGE * STAGE2_BYTES);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* g_ptr;
+
+  const int panel = blockIdx.x / n_split, split = blockIdx.x - panel * n_split;
+  const int nt0 = (int)((long)split * tiles_n / n_split), nt1 = (int)((long)(split + 1) * tiles_n / n_split);
+  const long m0 = (long)panel * BM2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = K / BK2;
+  const int total = (nt1 - nt0) * nk;
+
+  // bias for this block's column range -> LDS (read back in the epilogue)
+  for (int i = tid; i < (nt1 - nt0) * BN2; i += 512) lds_bias[i] = bias ? bias[nt0 * BN2 + i] : 0.f;
+
+  // per-lane global sources of the LDS-DMA pieces (1 KiB = 8 rows x 128 B per wave-instruction)
+  const unsigned short* a_src[4];
+  long w_off[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 8 * (4 * wave + j) + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    long ar = m0 + row;
+    if (ar >= M) ar = M - 1;           // rows past M only feed rows past M
+    a_src[j] = A + ar * lda + chunk * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 8 * (2 * wave + j) + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    w_off[j] = (long)row * K + chunk * 8;
+  }
+  auto issue = [&](int it) {
+    const int stage = it % NSTAGE;
+    const int nn = nt0 + it / nk, k0 = (it % nk) * BK2;
+    unsigned char* sa = lds + stage * STAGE2_BYTES + (4 * wave) * 1024;
+    unsigned char* sw = lds + stage * STAGE2_BYTES + A2_BYTES + (2 * wave) * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((g_ptr)(a_src[j] + k0), (lds_ptr)(sa + j * 1024), 16, 0, 0);
+    const unsigned short* wb = W + (long)nn * BN2 * K + k0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((g_ptr)(wb + w_off[j]), (lds_ptr)(sw + j * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (total > 0) issue(0);
+  if (total > 1) issue(1);
+  const int frow = lane & 15, fk = lane >> 4;
+  bool stores_pending = false;   // epilogue stores were issued after the youngest LDS-DMA group
+  for (int it = 0; it < total; ++it) {
+    // retire this wave's pieces of tile `it` (everything older than the youngest in-flight group)
+    if (it + 1 < total) {
+      if (stores_pending) wait_vmcnt<GLDS_PER_TILE + STORES_PER_TILE>();
+      else wait_vmcnt<GLDS_PER_TILE>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    stores_pending = false;
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < total) issue(it + 2);
+    const unsigned char* As = lds + (it % NSTAGE) * STAGE2_BYTES;
+    const unsigned char* Ws = As + A2_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(As + swz_off(wm * 64 + i * 16 + frow, ks * 4 + fk));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        wf[j] = *reinterpret_cast<const bf16x8*>(Ws + swz_off(wn * 64 + j * 16 + frow, ks * 4 + fk));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if ((it + 1) % nk == 0) {
+      const int nn = nt0 + it / nk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long m = m0 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
+          const float4 bv = *reinterpret_cast<const float4*>(lds_bias + (nn - nt0) * BN2 + nl);
+          f32x4 v = acc[i][j];
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+          epilogue_store4<EPI, true>(v, m, nn * BN2 + nl, 0x7fffffffffffffffL, N, nullptr, resid, pos, C,
+                                     rows_per_batch, valid_rows);
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      stores_pending = true;
+    }
+  }
+}
+
+static int pick_n_split(long panels, int tiles_n) {
+  // enough workgroups to fill 256 CUs a few times over, but keep the n-loop long
+  int s = 1;
+  while (panels * s < 1024 && s < tiles_n && tiles_n % (s * 2) == 0) s *= 2;
+  if (panels * s < 512 && tiles_n % 3 == 0 && s * 3 <= tiles_n) s *= 3;
+  return s;
+}
+
 int launch_gemm_bf16(const void* A, long lda, const void* W, const float* bias, const float* resid,
                      const float* pos, void* C, long M, int N, int K, int epi, int rows_per_batch,
-                     hipStream_t s) {
+                     hipStream_t s, int rows_padded_256) {
   GWW_REQUIRE(A && W && C, "gemm_bf16: NULL operand");
   GWW_REQUIRE(K % BK == 0 && K > 0, "gemm_bf16: K=%d must be a positive multiple of %d", K, BK);
   GWW_REQUIRE(N % 4 == 0 && N > 0, "gemm_bf16: N=%d must be a positive multiple of 4", N);
@@ -159,6 +305,28 @@ int launch_gemm_bf16(const void* A, long lda, const void* W, const float* bias, 
     valid_rows = rows_per_batch - 2;
   } else if (epi == EPI_RESID) {
     GWW_REQUIRE(resid != nullptr, "gemm_bf16: residual epilogue needs resid");
+  }
+  if (rows_padded_256 && N % BN2 == 0 && N <= 1536 && M >= 4096 && epi != EPI_CONV1) {
+    // large-M path; the caller has padded A / C / resid to a multiple of 256 rows.
+    // (EPI_CONV1 writes row m + 1 and keeps the bounds-checked kernel.)
+    const long panels = cdiv(M, BM2);
+    const int tn2 = N / BN2;
+    const int n_split = pick_n_split(panels, tn2);
+    dim3 grid2((unsigned)(panels * n_split)), block2(512);
+#define GWW_GEMM2_CASE(E)                                                                             \
+  case E:                                                                                             \
+    hipLaunchKernelGGL((k_gemm_bf16_v2<E>), grid2, block2, 0, s, (const unsigned short*)A, lda,       \
+                       (const unsigned short*)W, bias, resid, pos, C, M, N, K, rows_per_batch,        \
+                       valid_rows, tn2, n_split);                                                     \
+    break;
+    switch (epi) {
+      GWW_GEMM2_CASE(EPI_BIAS) GWW_GEMM2_CASE(EPI_GELU) GWW_GEMM2_CASE(EPI_RESID) GWW_GEMM2_CASE(EPI_CONV2)
+      default:
+        return fail(GWW_ERR_ARG, "gemm_bf16: unknown epilogue %d", epi);
+    }
+#undef GWW_GEMM2_CASE
+    GWW_LAUNCH_CHECK();
+    return GWW_OK;
   }
   dim3 grid((unsigned)n_tiles), block(256);
 #define GWW_GEMM_CASE(E)                                                                              \
@@ -229,5 +397,6 @@ using namespace gww;
 extern "C" int gww_gemm_bf16(const void* A, const void* W, const float* bias, const float* resid, void* C,
                              long M, int N, int K, int epilogue, void* stream) {
   GWW_REQUIRE(epilogue >= 0 && epilogue <= 2, "gww_gemm_bf16: epilogue must be 0, 1 or 2");
-  return launch_gemm_bf16(A, K, W, bias, resid, nullptr, C, M, N, K, epilogue, 0, (hipStream_t)stream);
+  return launch_gemm_bf16(A, K, W, bias, resid, nullptr, C, M, N, K, epilogue, 0, (hipStream_t)stream,
+                          M % 256 == 0);
 }

@@ -138,6 +138,18 @@ int gww_layernorm(const float* x, const float* w, const float* b, void* y, int o
  * f32 variant : everything fp32. */
 int gww_gemm_bf16(const void* A, const void* W, const float* bias, const float* resid, void* C,
                   long M, int N, int K, int epilogue, void* stream);
+/* A-stationary bf16 GEMM for K in {256, 384, 512}, N % 128 == 0 (QKV / fc1 / out_proj at
+ * whisper-tiny/base): C = epi(f(A) @ W^T + bias), C bf16, epilogue 0 (bias) or 1 (GELU).
+ *   ln_w == NULL : A is bf16 [M,K].
+ *   ln_w != NULL : A is the fp32 residual stream x [M,K]; the deferred residual add
+ *                  x_new = x + delta (delta bf16 [M,K] or NULL) and LayerNorm (eps 1e-5,
+ *                  HF:modeling_whisper.py:392,402) are fused into the operand build;
+ *                  x_new is written to x_out (fp32 [M,K], may be NULL, must not alias A).
+ * Rows of C must be ALLOCATED up to the next multiple of 256: whole 256-row panels are stored
+ * unconditionally (rows >= M are scratch). */
+int gww_gemm_astat_bf16(const void* A, const void* delta, float* x_out, const float* ln_w,
+                        const float* ln_b, const void* W, const float* bias, void* C, long M, int N,
+                        int K, int epilogue, void* stream);
 int gww_gemm_f32(const float* A, const float* W, const float* bias, const float* resid, float* C,
                  long M, int N, int K, int epilogue, void* stream);
 /* softmax(q k^T) v per head, q pre-scaled; qkv [B,T,3*d] (q|k|v), ctx [B,T,d]; head_dim 64 */

@@ -108,7 +108,9 @@ def test_cast_bf16_round_to_nearest_even(T, gww):
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 384), (1501, 1152, 384), (777, 384, 1536), (64, 1536, 384)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 384), (1501, 1152, 384), (777, 384, 1536), (64, 1536, 384),
+                                   # M % 256 == 0 and >= 4096: the persistent row-panel kernel (v2)
+                                   (4096, 384, 384), (5120, 1152, 384), (4352, 384, 1536), (4096, 1536, 384), (8192, 128, 128)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_bf16(T, gww, M, N, K, epi):
     from gw_whisper_amd import ops
@@ -131,6 +133,55 @@ def test_gemm_bf16(T, gww, M, N, K, epi):
     else:
         # bf16 out: one rounding of the exact result
         np.testing.assert_allclose(got, ref, atol=1e-5 * np.sqrt(K), rtol=2 ** -8)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 384), (1500, 1152, 384), (3000, 384, 384), (777, 1536, 384),
+                                   (512, 256, 256), (300, 512, 512), (5000, 1536, 384)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_gemm_astat_bf16(T, gww, M, N, K, epi):
+    """A panel held in registers, W through the LDS-DMA ring (gemm_astat.hip)."""
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(M * 3 + N + K + epi)
+    a = _bf(rng.standard_normal((M, K)))
+    w = _bf(rng.standard_normal((N, K)) / np.sqrt(K))
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    if epi == 1:
+        ref = oenc.gelu(ref)
+    c = ops.gemm_astat(T.from_numpy(a).cuda().bfloat16(), T.from_numpy(w).cuda().bfloat16(),
+                       T.from_numpy(bias).cuda(), epilogue=epi)
+    got = c.float().cpu().numpy()
+    assert got.shape == (M, N)
+    np.testing.assert_allclose(got, ref, atol=1e-5 * np.sqrt(K), rtol=2 ** -8)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 1152, 384), (1500, 1536, 384), (700, 512, 512)])
+@pytest.mark.parametrize("epi", [0, 1])
+@pytest.mark.parametrize("with_delta", [False, True])
+def test_gemm_astat_fused_layernorm(T, gww, M, N, K, epi, with_delta):
+    """Deferred residual add + LayerNorm folded into the operand build:
+    equals (x + delta) -> LN -> bf16 round -> GEMM, and x_new is written back exactly."""
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(M + N + K + epi)
+    x = (rng.standard_normal((M, K)) * 2 + 0.3).astype(np.float32)
+    dl = _bf(rng.standard_normal((M, K)) * 0.5) if with_delta else None
+    lw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    lb = (0.1 * rng.standard_normal(K)).astype(np.float32)
+    w = _bf(rng.standard_normal((N, K)) / np.sqrt(K))
+    bias = rng.standard_normal(N).astype(np.float32)
+    xn = x + dl if with_delta else x
+    h = _bf(oenc.layer_norm(xn.astype(np.float64), lw, lb).astype(np.float32))
+    ref = h.astype(np.float64) @ w.astype(np.float64).T + bias
+    if epi == 1:
+        ref = oenc.gelu(ref)
+    c, x_new = ops.gemm_astat(T.from_numpy(x).cuda(), T.from_numpy(w).cuda().bfloat16(), T.from_numpy(bias).cuda(),
+                              epilogue=epi, ln_w=T.from_numpy(lw).cuda(), ln_b=T.from_numpy(lb).cuda(),
+                              delta=T.from_numpy(dl).cuda().bfloat16() if with_delta else None, return_x=True)
+    np.testing.assert_array_equal(x_new.cpu().numpy(), xn.astype(np.float32))
+    got = c.float().cpu().numpy()
+    # a handful of LN outputs sit on a bf16 rounding tie and flip; budget one bf16 ulp of one operand
+    np.testing.assert_allclose(got, ref, atol=2e-2, rtol=2 ** -7)
+    assert np.sqrt(((got - ref) ** 2).mean()) < 4e-3   # ~ bf16 rounding of the O(1.4) outputs
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 64, 32), (300, 384, 384), (1501, 128, 96)])
