@@ -105,7 +105,7 @@ def kernel_breakdown(enc_name, B, dev):
         add("gemm_out_resid", lambda: ops.gemm(h, wo, bo, 2, resid=x32), B * 2 * T_TOK * d * d, M * d * 10)
         add("gemm_fc1_gelu", lambda: ops.gemm(h, w1, b1, 1), B * 2 * T_TOK * d * ffn, M * (d + ffn) * 2)
     if astat:
-        add("gemm_fc2", lambda: ops.gemm(f1, w2, bo, 0), B * 2 * T_TOK * d * ffn, M * (ffn * 2 + d * 2))
+        add("gemm_fc2", lambda: ops.gemm_fulln(f1, w2, bo, 0), B * 2 * T_TOK * d * ffn, M * (ffn * 2 + d * 2))
     else:
         add("gemm_fc2_resid", lambda: ops.gemm(f1, w2, bo, 2, resid=x32), B * 2 * T_TOK * d * ffn, M * (ffn * 2 + d * 8))
     return rows

@@ -277,8 +277,11 @@ extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, 
   else
     GWW_TRY(gemm(melT, C, e->c1w, e->c1w32, e->c1b, nullptr, nullptr, c1, (long)B * (Tin + 2), d, kConv1Kpad,
                  EPI_CONV1, Tin + 2));
-  GWW_TRY(gemm(c1, 2L * d, e->c2w, e->c2w32, e->c2b, nullptr, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2,
-               T + 1));
+  if (bf && (d == 384 || d == 512))
+    GWW_TRY(launch_gemm_fulln(c1, 2L * d, e->c2w, e->c2b, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2, T + 1, s));
+  else
+    GWW_TRY(gemm(c1, 2L * d, e->c2w, e->c2w32, e->c2b, nullptr, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2,
+                 T + 1));
   float* xc = x;                       // current residual stream
   const void* pending = nullptr;       // bf16 delta not yet added to xc (A-stationary path)
   if (astat) {
@@ -296,7 +299,7 @@ extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, 
       GWW_TRY(launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, L.wo, L.bo, d1, M, d, d, EPI_BIAS, 0, s));
       GWW_TRY(launch_gemm_astat(xc, d, d1, xn, L.ln2w, L.ln2b, L.w1, L.b1, f1, M, F, d, EPI_GELU, 0, s));
       { float* t = xc; xc = xn; xn = t; }
-      GWW_TRY(launch_gemm_bf16(f1, F, L.w2, L.b2, nullptr, nullptr, d2, M, d, F, EPI_BIAS, 0, s, 1));
+      GWW_TRY(launch_gemm_fulln(f1, F, L.w2, L.b2, nullptr, d2, M, d, F, EPI_BIAS, 0, s));
       pending = d2;
     }
   } else {

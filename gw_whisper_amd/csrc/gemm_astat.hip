@@ -53,6 +53,29 @@ __device__ __forceinline__ void as_wait_vmcnt() {
 
 enum : int { AMODE_BF16 = 0, AMODE_LN = 1 };
 
+// ---- optional in-kernel phase stamps (diagnostic build only: -DGWW_STAMP); totals per phase in cycles
+#ifdef GWW_STAMP
+__device__ unsigned long long g_stamp[8];
+#define STAMP_DECL unsigned long long _t0 = __builtin_amdgcn_s_memtime(); unsigned long long _acc[6] = {0, 0, 0, 0, 0, 0};
+#define STAMP(i)                                                   \
+  do {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    const unsigned long long _t1 = __builtin_amdgcn_s_memtime();   \
+    _acc[i] += _t1 - _t0;                                          \
+    _t0 = _t1;                                                     \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+#define STAMP_FLUSH                                                                  \
+  if (lane == 0) {                                                                   \
+    for (int _q = 0; _q < 6; ++_q) atomicAdd(&g_stamp[_q], _acc[_q]);                \
+    atomicAdd(&g_stamp[7], 1ull);                                                    \
+  }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
 // KT = K / 64 (k-tiles); A fragments: af[4 S + j] holds k = 64 S + 32 hh + 8 j .. +7 of row m.
 template <int EPI, int AMODE, int KT>
 __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __restrict__ Aany, long lda,
@@ -105,7 +128,15 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __rest
   };
 
   for (int i = tid; i < (nt1 - nt0) * AS_BN; i += AS_THREADS) lds_bias[i] = bias ? bias[nt0 * AS_BN + i] : 0.f;
+  // De-phase the CUs: every workgroup of the first resident round starts (blockIdx % 8) * stagger
+  // later, so the HBM-read prologues, the L2-fed MFMA loops and the store epilogues of different
+  // CUs overlap in time instead of all CUs hammering the same resource in lock step.
+  if (dbg >> 8) {
+    const int steps = (blockIdx.x < 256) ? (blockIdx.x & 7) * (dbg >> 8) : 0;
+    for (int q = 0; q < steps; ++q) __builtin_amdgcn_s_sleep(127);   // ~3.4 us per step
+  }
 
+  STAMP_DECL
   // ---- A fragments (whole K) for this wave's 32 rows
   bf16x8 af[KT * 4];
   long grow[4];   // clamped global rows this lane touches in the coalesced passes
@@ -156,7 +187,7 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __rest
       }
       return v;
     };
-#pragma unroll 2
+#pragma unroll 6
     for (int hs = 0; hs < 2 * KT; ++hs) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -167,6 +198,7 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __rest
         s2[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
       }
     }
+    STAMP(0);
     float mean[4], rstd[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -182,7 +214,7 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __rest
     __syncthreads();                 // LN params staged (no LDS-DMA in flight yet)
 #pragma unroll
     for (int hs = 0; hs < 2 * KT; ++hs) {
-      __builtin_amdgcn_sched_barrier(0);
+      if ((hs & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // <= 4 half slices (64 fp32) in flight per lane
       const float4 g = *reinterpret_cast<const float4*>(lds_lnw + 32 * hs + 4 * cchunk);
       const float4 bb = *reinterpret_cast<const float4*>(lds_lnb + 32 * hs + 4 * cchunk);
 #pragma unroll
@@ -205,6 +237,7 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __rest
   }
   // every ordinary load / store above is retired before the LDS-DMA ring starts counting
   as_wait_vmcnt<0>();
+  STAMP(1);
   if constexpr (AMODE == AMODE_LN) __syncthreads();   // LN params (aliased onto the ring) no longer needed
 #pragma unroll
   for (int p = 0; p < AS_D; ++p)
@@ -233,6 +266,7 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __rest
         as_wait_vmcnt<0>();   // tail: fewer groups in flight than the constant assumes
       }
       __builtin_amdgcn_s_barrier();
+      STAMP(2);
       if (it + AS_D < total) issue(it + AS_D);
       const unsigned char* Ws = lds + (it % AS_NST) * AS_W_BYTES;
       if (dbg & 2) continue;   // tuning aid: ring only
@@ -245,6 +279,7 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __rest
         for (int t = 0; t < 4; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t], af[4 * S + j], acc[t], 0, 0, 0);
       }
+      STAMP(3);
     }
     // ---- epilogue: bias (+GELU) -> bf16 -> wave-private LDS transpose -> whole-line stores
     const int nn = nt0 + nti;
@@ -290,7 +325,9 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __rest
         *reinterpret_cast<u32x4*>(dst) = u;
       }
     }
+    STAMP(4);
   }
+  STAMP_FLUSH
 }
 
 static int as_pick_split(long panels, int tiles_n) {
@@ -368,3 +405,14 @@ extern "C" int gww_gemm_astat_bf16(const void* A, const void* delta, float* x_ou
   return launch_gemm_astat(A, K, delta, x_out, ln_w, ln_b, W, bias, C, M, N, K, epilogue, 0, (hipStream_t)stream,
                            dbg_panel ? (M + 255) / 256 * 256 : 0);
 }
+
+#ifdef GWW_STAMP
+extern "C" int gww_debug_stamps(unsigned long long* out8, int reset) {
+  GWW_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(gww::g_stamp), sizeof(unsigned long long) * 8));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    GWW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gww::g_stamp), z, sizeof(z)));
+  }
+  return GWW_OK;
+}
+#endif

@@ -129,6 +129,21 @@ def gemm_astat(a: torch.Tensor, w: torch.Tensor, bias=None, epilogue: int = 0, l
     return (c[:M], x_out) if return_x else c[:M]
 
 
+def gemm_fulln(a: torch.Tensor, w: torch.Tensor, bias=None, epilogue: int = 0) -> torch.Tensor:
+    """Full-N bf16 GEMM (N in {384, 512}, K % 32 == 0): complete output rows per workgroup."""
+    a = _dev(a, torch.bfloat16, "A")
+    w = _dev(w, torch.bfloat16, "W")
+    M, K = a.shape
+    N = w.shape[0]
+    Mp = (M + 127) // 128 * 128
+    c = torch.empty((Mp, N), dtype=torch.bfloat16, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib().gww_gemm_fulln_bf16(a.data_ptr(), w.data_ptr(),
+                                        _dev(bias, torch.float32).data_ptr() if bias is not None else None,
+                                        c.data_ptr(), M, N, K, epilogue, _stream()), "gww_gemm_fulln_bf16")
+    return c[:M]
+
+
 def attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:
     """qkv [B, T, 3 d] (q pre-scaled) -> ctx [B, T, d]; bf16 or fp32."""
     bf = qkv.dtype == torch.bfloat16

@@ -150,6 +150,11 @@ int gww_gemm_bf16(const void* A, const void* W, const float* bias, const float* 
 int gww_gemm_astat_bf16(const void* A, const void* delta, float* x_out, const float* ln_w,
                         const float* ln_b, const void* W, const float* bias, void* C, long M, int N,
                         int K, int epilogue, void* stream);
+/* Full-N bf16 GEMM for the long-K, N = d contractions (fc2, conv2): one workgroup owns complete
+ * 128-row x N output panels, so A is read from HBM once.  N in {384, 512}, K % 32 == 0, C bf16
+ * [M,N] with rows allocated up to the next multiple of 128; epilogue 0 (bias) or 1 (GELU). */
+int gww_gemm_fulln_bf16(const void* A, const void* W, const float* bias, void* C, long M, int N, int K,
+                        int epilogue, void* stream);
 int gww_gemm_f32(const float* A, const float* W, const float* bias, const float* resid, float* C,
                  long M, int N, int K, int epilogue, void* stream);
 /* softmax(q k^T) v per head, q pre-scaled; qkv [B,T,3*d] (q|k|v), ctx [B,T,d]; head_dim 64 */

@@ -184,6 +184,25 @@ def test_gemm_astat_fused_layernorm(T, gww, M, N, K, epi, with_delta):
     assert np.sqrt(((got - ref) ** 2).mean()) < 4e-3   # ~ bf16 rounding of the O(1.4) outputs
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 384, 64), (1500, 384, 1536), (777, 384, 1152), (300, 512, 2048), (4000, 384, 128)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_gemm_fulln_bf16(T, gww, M, N, K, epi):
+    """Complete output rows per workgroup, A streamed once (gemm_fulln.hip)."""
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(M * 5 + N + K + epi)
+    a = _bf(rng.standard_normal((M, K)))
+    w = _bf(rng.standard_normal((N, K)) / np.sqrt(K))
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    if epi == 1:
+        ref = oenc.gelu(ref)
+    c = ops.gemm_fulln(T.from_numpy(a).cuda().bfloat16(), T.from_numpy(w).cuda().bfloat16(), T.from_numpy(bias).cuda(),
+                       epilogue=epi)
+    got = c.float().cpu().numpy()
+    assert got.shape == (M, N)
+    np.testing.assert_allclose(got, ref, atol=1e-5 * np.sqrt(K), rtol=2 ** -8)
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 64, 32), (300, 384, 384), (1501, 128, 96)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_f32(T, gww, M, N, K, epi):
