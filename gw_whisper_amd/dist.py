@@ -1,0 +1,90 @@
+"""Data-parallel plumbing: one process per GPU, ``torch.distributed``
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" for the CPU tests).
+
+The reference has no multi-GPU code at all (``Signal_vs_Noise/src/train.py:214`` picks one
+device).  Segments / sliding windows are independent, so
+
+* inference (``MLGWSC-1/inference.py:454-489``): a static, contiguous partition of the segment
+  (or window) index range -- contiguous so the time-ordered trigger clustering
+  (``inference.py:140-166``) can run per rank -- with batch boundaries aligned to the global
+  batch grid (``global index // batch``) so results do not depend on the number of ranks;
+  NO collective on the data path, one gather of the scores at the end;
+* training: identical frozen base on every rank, replicated DoRA + head parameters, ONE flat
+  fp32 bucket ``all_reduce(SUM)`` of the trainable gradients per step (<= 11.4 MB: latency
+  bound over xGMI), divided by the world size.
+"""
+
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend: str | None = None) -> Tuple[int, int, int]:
+    """Initialise from the torchrun environment; returns (rank, world, local_rank)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int, batch: int = 1) -> Tuple[int, int]:
+    """Contiguous [start, stop) of this rank, aligned to whole global batches."""
+    n_batches = (n_items + batch - 1) // batch
+    per, extra = divmod(n_batches, world)
+    b0 = rank * per + min(rank, extra)
+    b1 = b0 + per + (1 if rank < extra else 0)
+    return min(b0 * batch, n_items), min(b1 * batch, n_items)
+
+
+def gather_concat(local: torch.Tensor, n_items: int, rank: int, world: int, batch: int = 1) -> torch.Tensor | None:
+    """Gather the per-rank result rows (in ``shard_range`` order) on rank 0."""
+    if world == 1:
+        return local
+    sizes = [shard_range(n_items, r, world, batch) for r in range(world)]
+    pad = max(b - a for a, b in sizes)
+    buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    buf[: local.shape[0]] = local
+    out = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, out, dst=0)
+    if rank != 0:
+        return None
+    return torch.cat([o[: b - a] for o, (a, b) in zip(out, sizes)], dim=0)
+
+
+class FlatGradBucket:
+    """One flat fp32 buffer over the trainable parameters' gradients: a single
+    ``all_reduce(SUM)`` per step, then an in-place divide by the world size."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:          # gradients become views into the flat buffer
+            p.grad = self.flat[off: off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, world: int):
+        if world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(world)

@@ -121,3 +121,74 @@ def test_config1_tiny_against_reference_golden(T, gww, golden, precision, tol_la
     assert e2 < tol_logit and e1 < tol_logit
     np.testing.assert_array_equal(oheads.binary_labels(lg2), g["two_channel_labels"])
     np.testing.assert_array_equal(oheads.binary_labels(lg1), g["one_channel_labels"])
+
+
+def test_dora_adapted_encoder_matches_oracle(T, gww):
+    """get_peft_model(use_dora=True) on k_proj/v_proj with non-trivial A, B, m: the HIP merge
+    kernel + packed forward equals the oracle run on oracle-merged weights
+    (peft 0.12.0 dora.py formula), and an untouched adapter is the identity."""
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    from gw_whisper_amd.peft import LoraConfig, get_peft_model
+    from oracle import dora as odora
+    cfg = WhisperConfig(128, 2, 2, 512)
+    sd = synth.encoder_state_dict(128, 2, 2, 512, seed=3)
+    mel = olm.log_mel(synth.strain_segments(2, seed=21))
+    base = oenc.encoder_forward(sd, mel, oenc.EncCfg(128, 2, 2, 512), dtype=np.float64)
+    enc = WhisperEncoder.from_numpy_state_dict(sd, cfg, precision="fp32")
+    targets = [f"layers.{i}.self_attn.{p}" for i in range(2) for p in ("k_proj", "v_proj")]
+    peft = get_peft_model(enc, LoraConfig(use_dora=True, r=8, lora_alpha=32, target_modules=targets)).cuda()
+    with T.no_grad():
+        out0 = peft(T.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    np.testing.assert_allclose(out0, base, atol=2e-4, rtol=1e-4)          # identity at init
+    sd2 = dict(sd)
+    with T.no_grad():
+        for j, name in enumerate(targets):
+            lin = peft.base_model.model.get_submodule(name)
+            W0 = sd[name + ".weight"]
+            A, B, m = synth.dora_adapter(128, 128, 8, W0, seed=50 + j)
+            lin.lora_A["default"].weight.copy_(T.from_numpy(A))
+            lin.lora_B["default"].weight.copy_(T.from_numpy(B))
+            lin.lora_magnitude_vector["default"].weight.copy_(T.from_numpy(m))
+            sd2[name + ".weight"] = odora.dora_merge(W0.astype(np.float64), A.astype(np.float64),
+                                                     B.astype(np.float64), m.astype(np.float64), 4.0)
+        out1 = peft(T.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    ref1 = oenc.encoder_forward(sd2, mel, oenc.EncCfg(128, 2, 2, 512), dtype=np.float64)
+    assert np.abs(ref1 - base).max() > 1e-2, "the adapter must actually change the output"
+    np.testing.assert_allclose(out1, ref1, atol=2e-4, rtol=1e-4)
+
+
+def test_two_channel_model_on_gpu_matches_reference_logits(T, gww, golden):
+    """The counterpart of Signal_vs_Noise/src/model.py run end to end on the GPU (HIP front end,
+    HIP encoder, torch MLP head): logits within 1e-3 of the reference's CPU logits, labels exact."""
+    from gw_whisper_amd import ops
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    from gw_whisper_amd.models import one_channel_ligo_binary_classifier, two_channel_ligo_binary_classifier
+    g = golden("config1.npz")
+    sd = synth.named_encoder_state_dict("tiny", seed=0)
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig.named("tiny"), precision="bf16")
+    m2 = two_channel_ligo_binary_classifier(enc)
+    m1 = one_channel_ligo_binary_classifier(enc)
+    head2 = synth.head_state_dict([768, 1024, 512, 256, 1], seed=0)
+    head2["6.bias"] = head2["6.bias"] + g["two_channel_bias_shift"]
+    head1 = synth.head_state_dict([384, 512, 256, 128, 64, 1], seed=1)
+    head1["8.bias"] = head1["8.bias"] + g["one_channel_bias_shift"]
+    m2.classifier.load_state_dict({k: T.from_numpy(v) for k, v in head2.items()})
+    m1.classifier.load_state_dict({k: T.from_numpy(v) for k, v in head1.items()})
+    m2.cuda().eval(); m1.cuda().eval()
+    n = 64
+    h1 = synth.strain_segments(n, seed=0)
+    l1 = synth.strain_segments(n, seed=1)
+    t = np.arange(16000, dtype=np.float32) / 16000.0
+    for i in range(0, n, 2):
+        s = (3.0 * np.sin(2 * np.pi * (40.0 + 200.0 * t * (1 + 0.05 * i)) * t) * np.exp(-((t - 0.6) / 0.15) ** 2))
+        h1[i] += s.astype(np.float32)
+        l1[i] += s.astype(np.float32)
+    with T.no_grad():
+        a = ops.logmel(T.from_numpy(h1).cuda())
+        b = ops.logmel(T.from_numpy(l1).cuda())
+        lg2 = m2(a, b).cpu().numpy()
+        lg1 = m1(b).cpu().numpy()
+    assert np.abs(lg2 - g["two_channel_logits"]).max() < 1e-3
+    assert np.abs(lg1 - g["one_channel_logits"]).max() < 1e-3
+    np.testing.assert_array_equal(oheads.binary_labels(lg2), g["two_channel_labels"])
+    np.testing.assert_array_equal(oheads.binary_labels(lg1), g["one_channel_labels"])

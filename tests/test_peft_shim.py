@@ -1,0 +1,95 @@
+"""peft stand-in: runtime parameter names, trainable-parameter selection and the on-disk
+adapter schema against the adapters the reference ships (tests/golden/adapter_schema.json).
+CPU only (no kernels run)."""
+
+import fnmatch
+import json
+import os
+
+import pytest
+import torch
+
+from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+from gw_whisper_amd.peft import LoraConfig, PeftModel, get_peft_model
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _targets(enc, pats):
+    return [n for n, _ in enc.named_modules() if any(fnmatch.fnmatch(n, p) for p in pats)]
+
+
+def test_reference_recipe_names_and_counts():
+    """Signal_vs_Noise/src/train.py:230-237,263-267: fnmatch targets, get_peft_model,
+    requires_grad = 'lora' in name  ->  12 modules, 78 336 trainable parameters on tiny."""
+    enc = WhisperEncoder(WhisperConfig.named("tiny"))
+    pats = ["layers.*.self_attn.q_proj", "layers.*.self_attn.k_proj", "layers.*.self_attn.v_proj",
+            "layers.*.self_attn.o_proj"]
+    targets = _targets(enc, pats)
+    assert len(targets) == 12
+    peft = get_peft_model(enc, LoraConfig(use_dora=True, r=8, lora_alpha=32, target_modules=targets))
+    for name, p in peft.named_parameters():
+        p.requires_grad = "lora" in name
+    names = dict(peft.named_parameters())
+    assert "base_model.model.layers.0.self_attn.k_proj.base_layer.weight" in names
+    assert "base_model.model.layers.0.self_attn.k_proj.lora_A.default.weight" in names
+    assert "base_model.model.layers.0.self_attn.k_proj.lora_B.default.weight" in names
+    assert "base_model.model.layers.0.self_attn.k_proj.lora_magnitude_vector.default.weight" in names
+    trainable = sum(p.numel() for p in peft.parameters() if p.requires_grad)
+    assert trainable == 78336
+    assert peft.config.d_model == 384          # src/model.py:11 reads encoder.config.d_model
+    # identity at init: B = 0 and m = ||W0||
+    lin = peft.base_model.model.layers[0].self_attn.k_proj
+    assert torch.count_nonzero(lin.lora_B["default"].weight) == 0
+    torch.testing.assert_close(lin.lora_magnitude_vector["default"].weight,
+                               torch.linalg.norm(lin.base_layer.weight, dim=1))
+
+
+def test_save_pretrained_matches_shipped_schema(tmp_path):
+    with open(os.path.join(GOLDEN, "adapter_schema.json")) as f:
+        shipped = json.load(f)
+    enc = WhisperEncoder(WhisperConfig.named("tiny"))
+    targets = shipped["adapter_config.json"]["target_modules"]       # k_proj + v_proj of 4 layers
+    peft = get_peft_model(enc, LoraConfig(use_dora=True, r=8, lora_alpha=32, target_modules=targets,
+                                          base_model_name_or_path="openai/whisper-tiny"))
+    peft.save_pretrained(str(tmp_path))
+    from safetensors import safe_open
+    with safe_open(str(tmp_path / "adapter_model.safetensors"), "pt") as f:
+        got = {k: {"shape": list(f.get_tensor(k).shape), "dtype": str(f.get_tensor(k).dtype).replace("torch.", "")}
+               for k in f.keys()}
+    assert got == shipped["adapter_model.safetensors"]
+    cfg = json.load(open(tmp_path / "adapter_config.json"))
+    ref = shipped["adapter_config.json"]
+    assert set(cfg) == set(ref), set(cfg) ^ set(ref)
+    for k in ref:
+        if k == "target_modules":
+            assert sorted(cfg[k]) == sorted(ref[k])
+        else:
+            assert cfg[k] == ref[k], k
+
+
+def test_from_pretrained_round_trip(tmp_path):
+    torch.manual_seed(0)
+    enc = WhisperEncoder(WhisperConfig(128, 2, 2, 512))
+    targets = _targets(enc, ["layers.*.self_attn.k_proj", "layers.*.self_attn.v_proj"])
+    peft = get_peft_model(enc, LoraConfig(use_dora=True, r=4, lora_alpha=16, target_modules=targets))
+    with torch.no_grad():
+        for n, p in peft.named_parameters():
+            if "lora_" in n:
+                p.add_(torch.randn_like(p) * 0.1)
+    peft.save_pretrained(str(tmp_path))
+    enc2 = WhisperEncoder(WhisperConfig(128, 2, 2, 512))
+    enc2.load_state_dict(enc.state_dict() if False else {k.replace(".base_layer", ""): v for k, v in enc.state_dict().items()
+                                                         if "lora_" not in k})
+    peft2 = PeftModel.from_pretrained(enc2, str(tmp_path))
+    a, b = peft.state_dict(), peft2.state_dict()
+    assert a.keys() == b.keys()
+    for k in a:
+        torch.testing.assert_close(a[k], b[k])
+    assert not any(p.requires_grad for n, p in peft2.named_parameters() if "lora_" in n)   # inference mode
+
+
+def test_unknown_target_raises():
+    enc = WhisperEncoder(WhisperConfig(128, 1, 2, 512))
+    with pytest.raises(ValueError, match="not found"):
+        get_peft_model(enc, LoraConfig(use_dora=True, target_modules=["layers.0.self_attn.o_proj"]))
