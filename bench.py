@@ -91,11 +91,13 @@ def kernel_breakdown(enc_name, B, dev):
     astat = d in (384, 512)
     if astat:
         # the encoder uses the A-stationary kernels with LayerNorm fused into QKV / fc1
-        add("ln+gemm_qkv", lambda: ops.gemm_astat(x32, wqkv, bqkv, 0, ln_w=lnw, ln_b=lnb),
+        wq_f, uq, cq = ops.ln_fold_weights(wqkv.float(), lnw, lnb, bqkv)
+        w1_f, u1, c1 = ops.ln_fold_weights(w1.float(), lnw, lnb, b1)
+        add("ln+gemm_qkv", lambda: ops.gemm_astat(x32, wq_f, None, 0, ln=(uq, cq)),
             B * 2 * T_TOK * d * 3 * d, M * d * 4 + M * 3 * d * 2)
         add("attention", lambda: ops.attention(qkv, H), B * fl["attn"], M * 4 * d * 2)
         add("gemm_out", lambda: ops.gemm_astat(h, wo, bo, 0), B * 2 * T_TOK * d * d, M * d * 4)
-        add("resid+ln+gemm_fc1_gelu", lambda: ops.gemm_astat(x32, w1, b1, 1, ln_w=lnw, ln_b=lnb, delta=h, return_x=True),
+        add("resid+ln+gemm_fc1_gelu", lambda: ops.gemm_astat(x32, w1_f, None, 1, ln=(u1, c1), delta=h, return_x=True),
             B * 2 * T_TOK * d * ffn, M * d * 10 + M * ffn * 2)
     else:
         add("layernorm", lambda: ops.layernorm(x32, lnw, lnb, out_bf16=True), 0, M * d * 6)

@@ -93,8 +93,10 @@ int launch_layernorm(const float* x, const float* w, const float* b, void* y, in
                      long M, int d, hipStream_t s, const void* delta_bf16 = nullptr);
 int launch_layernorm_rows(const float* x, long row_stride, const float* w, const float* b, float* y,
                           long M, int d, hipStream_t s, const void* delta_bf16 = nullptr);
-int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, const float* ln_w,
-                      const float* ln_b, const void* W, const float* bias, void* C, long M, int N, int K,
+int launch_ln_fold(const float* w, const float* g, const float* bl, const float* bias, float scale, int N, int K,
+                   void* wp, float* u, float* cb, hipStream_t s);
+int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, const float* ln_u,
+                      const float* ln_cb, const void* W, const float* bias, void* C, long M, int N, int K,
                       int epi, int rows_per_batch, hipStream_t s, long c_panel_rows = 0);
 int launch_cast_f32_bf16(const float* x, void* y, long n, hipStream_t s);
 int launch_pack_weight(const float* w, void* out, int out_bf16, int N, int C, int taps, int Kpad,

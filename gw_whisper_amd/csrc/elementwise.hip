@@ -172,6 +172,45 @@ int launch_scale_copy(const float* in, float* out, int n, float scale, hipStream
   return GWW_OK;
 }
 
+// ---------------------------------------------------------------- LayerNorm folding
+// For the GEMMs that apply LayerNorm algebraically (gemm_astat.hip): per output row n
+//   W'[n][k] = bf16(scale * g[k] * W[n][k]),  u[n] = sum_k W'[n][k],
+//   cb[n]    = scale * (bias[n] + sum_k b_ln[k] * W[n][k])
+__global__ __launch_bounds__(256) void k_ln_fold(const float* __restrict__ w, const float* __restrict__ g,
+                                                 const float* __restrict__ bl, const float* __restrict__ bias,
+                                                 float scale, int K, unsigned short* __restrict__ wp,
+                                                 float* __restrict__ u, float* __restrict__ cb) {
+  __shared__ float red[8];
+  const int n = blockIdx.x;
+  float su = 0.f, sc = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float wv = w[(long)n * K + k];
+    const unsigned short q = f2bf(scale * g[k] * wv);
+    wp[(long)n * K + k] = q;
+    su += bf2f(q);
+    sc = fmaf(bl[k], wv, sc);
+  }
+  su = wave_sum(su);
+  sc = wave_sum(sc);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = su;
+    red[4 + (threadIdx.x >> 6)] = sc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u[n] = red[0] + red[1] + red[2] + red[3];
+    cb[n] = scale * ((bias ? bias[n] : 0.f) + red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
+int launch_ln_fold(const float* w, const float* g, const float* bl, const float* bias, float scale, int N, int K,
+                   void* wp, float* u, float* cb, hipStream_t s) {
+  hipLaunchKernelGGL(k_ln_fold, dim3((unsigned)N), dim3(256), 0, s, w, g, bl, bias, scale, K,
+                     reinterpret_cast<unsigned short*>(wp), u, cb);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
 // ---------------------------------------------------------------- DoRA merge (K11)
 // peft 0.12.0 tuners/lora/dora.py: W' = W0 + s B A ; n = ||W'||_2 per output row ;
 // W_eff = (m / n)[:, None] * W'.  One workgroup per output row; fp32.
@@ -214,6 +253,13 @@ extern "C" int gww_dora_merge_f32(const float* w0, const float* a, const float* 
                      (hipStream_t)stream, w0, a, b, m, scaling, d_in, r, w_eff, norm_out);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
+}
+
+extern "C" int gww_ln_fold_weights(const float* w, const float* ln_w, const float* ln_b, const float* bias, float scale,
+                                   int N, int K, void* w_folded_bf16, float* u, float* cb, void* stream) {
+  GWW_REQUIRE(w && ln_w && ln_b && w_folded_bf16 && u && cb, "gww_ln_fold_weights: NULL argument");
+  GWW_REQUIRE(N > 0 && K > 0, "gww_ln_fold_weights: bad shape");
+  return launch_ln_fold(w, ln_w, ln_b, bias, scale, N, K, w_folded_bf16, u, cb, (hipStream_t)stream);
 }
 
 extern "C" int gww_layernorm(const float* x, const float* w, const float* b, void* y, int out_bf16, long M,

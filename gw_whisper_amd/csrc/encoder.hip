@@ -33,6 +33,9 @@ struct LayerW {
   // fp32 panels (parity path)
   float *wqkv32, *wo32, *w132, *w232;
   float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
+  // LayerNorm-folded panels for the A-stationary GEMMs (gain folded into W, see gemm_astat.hip)
+  unsigned short *wqkv_ln, *w1_ln;
+  float *uqkv, *cbqkv, *u1, *cb1;
 };
 
 constexpr int kConv1Kpad = 256;   // 3 * 80 = 240 padded to a multiple of 64
@@ -71,7 +74,8 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
   const size_t o_c1w32 = take((size_t)d * kConv1Kpad * 4), o_c2w32 = take((size_t)d * 3 * d * 4);
   const size_t o_c1b = take(d * 4), o_c2b = take(d * 4), o_pos = take((size_t)T * d * 4);
   const size_t o_lnw = take(d * 4), o_lnb = take(d * 4);
-  struct LO { size_t wqkv, wo, w1, w2, wqkv32, wo32, w132, w232, bqkv, bo, b1, b2, ln1w, ln1b, ln2w, ln2b; };
+  struct LO { size_t wqkv, wo, w1, w2, wqkv32, wo32, w132, w232, bqkv, bo, b1, b2, ln1w, ln1b, ln2w, ln2b,
+                     wqkv_ln, w1_ln, uqkv, cbqkv, u1, cb1; };
   std::vector<LO> lo(L);
   for (int i = 0; i < L; ++i) {
     lo[i].wqkv = take((size_t)3 * d * d * 2);
@@ -90,6 +94,12 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
     lo[i].ln1b = take(d * 4);
     lo[i].ln2w = take(d * 4);
     lo[i].ln2b = take(d * 4);
+    lo[i].wqkv_ln = take((size_t)3 * d * d * 2);
+    lo[i].w1_ln = take((size_t)F * d * 2);
+    lo[i].uqkv = take(3 * d * 4);
+    lo[i].cbqkv = take(3 * d * 4);
+    lo[i].u1 = take(F * 4);
+    lo[i].cb1 = take(F * 4);
   }
   hipError_t err = hipMalloc(&e->blob, off);
   if (err != hipSuccess) {
@@ -126,6 +136,12 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
     w.ln1b = (float*)(p + lo[i].ln1b);
     w.ln2w = (float*)(p + lo[i].ln2w);
     w.ln2b = (float*)(p + lo[i].ln2b);
+    w.wqkv_ln = (unsigned short*)(p + lo[i].wqkv_ln);
+    w.w1_ln = (unsigned short*)(p + lo[i].w1_ln);
+    w.uqkv = (float*)(p + lo[i].uqkv);
+    w.cbqkv = (float*)(p + lo[i].cbqkv);
+    w.u1 = (float*)(p + lo[i].u1);
+    w.cb1 = (float*)(p + lo[i].cb1);
   }
   *out = e;
   return GWW_OK;
@@ -189,6 +205,12 @@ extern "C" int gww_encoder_set_weights(gww_encoder* e, const gww_enc_globals* g,
     GWW_TRY(launch_scale_copy(L.ln1_b, w.ln1b, d, 1.f, s));
     GWW_TRY(launch_scale_copy(L.ln2_w, w.ln2w, d, 1.f, s));
     GWW_TRY(launch_scale_copy(L.ln2_b, w.ln2b, d, 1.f, s));
+    // gain-folded panels + correction vectors for the algebraic LayerNorm of the A-stationary GEMMs
+    GWW_TRY(launch_ln_fold(L.q_w, L.ln1_w, L.ln1_b, L.q_b, qs, d, d, w.wqkv_ln, w.uqkv, w.cbqkv, s));
+    GWW_TRY(launch_ln_fold(L.k_w, L.ln1_w, L.ln1_b, nullptr, 1.f, d, d, w.wqkv_ln + dd, w.uqkv + d, w.cbqkv + d, s));
+    GWW_TRY(launch_ln_fold(L.v_w, L.ln1_w, L.ln1_b, L.v_b, 1.f, d, d, w.wqkv_ln + 2 * dd, w.uqkv + 2 * d,
+                           w.cbqkv + 2 * d, s));
+    GWW_TRY(launch_ln_fold(L.fc1_w, L.ln2_w, L.ln2_b, L.fc1_b, 1.f, F, d, w.w1_ln, w.u1, w.cb1, s));
   }
   e->ready = true;
   return GWW_OK;
@@ -292,12 +314,12 @@ extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, 
     void* d2 = base + w.d2;
     for (int i = 0; i < e->cfg.n_layers; ++i) {
       const LayerW& L = e->layers[i];
-      GWW_TRY(launch_gemm_astat(xc, d, pending, pending ? xn : nullptr, L.ln1w, L.ln1b, L.wqkv, L.bqkv, qkv, M,
+      GWW_TRY(launch_gemm_astat(xc, d, pending, pending ? xn : nullptr, L.uqkv, L.cbqkv, L.wqkv_ln, nullptr, qkv, M,
                                 3 * d, d, EPI_BIAS, 0, s));
       if (pending) { float* t = xc; xc = xn; xn = t; }
       GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s));
       GWW_TRY(launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, L.wo, L.bo, d1, M, d, d, EPI_BIAS, 0, s));
-      GWW_TRY(launch_gemm_astat(xc, d, d1, xn, L.ln2w, L.ln2b, L.w1, L.b1, f1, M, F, d, EPI_GELU, 0, s));
+      GWW_TRY(launch_gemm_astat(xc, d, d1, xn, L.u1, L.cb1, L.w1_ln, nullptr, f1, M, F, d, EPI_GELU, 0, s));
       { float* t = xc; xc = xn; xn = t; }
       GWW_TRY(launch_gemm_fulln(f1, F, L.w2, L.b2, nullptr, d2, M, d, F, EPI_BIAS, 0, s));
       pending = d2;

@@ -11,11 +11,17 @@
 //     for the WHOLE K in registers as MFMA operand fragments (K/16 x 4 VGPRs = 96 at
 //     K = 384), read from HBM once, in whole 128-byte lines (8 lanes per row), and
 //     transposed into fragment order through a small wave-private LDS slice.
-//   * fused prologue (AMODE_LN): A = LayerNorm(x [+ delta]) built from the fp32 residual
-//     stream; the deferred residual add x += delta (the bf16 output of the previous
-//     out_proj / fc2 GEMM) is folded in and x is written back once.  The LayerNorm
-//     kernel, its bf16 round trip and the residual read-modify-write of the GEMM
-//     epilogues all disappear; HBM traffic is unchanged.
+//   * fused prologue (AMODE_LN): the deferred residual add x_new = x + delta (delta = bf16
+//     output of the previous out_proj / fc2 GEMM) and LayerNorm are folded into the GEMM in
+//     ONE pass over x.  LayerNorm is applied algebraically: the operand is the raw shifted
+//     row a = bf16(x_new - c_m) (c_m = mean of the row's first 32 values, so |a| ~ sigma), the
+//     gain is folded into the packed weight W' = bf16(g * W) and
+//         out[m][n] = rstd_m * (acc[m][n] - mean'_m * u[n]) + cb[n],
+//         u[n] = sum_k W'[n][k],   cb[n] = bias[n] + sum_k b_ln[k] W[n][k]
+//     with the exact fp32 row statistics mean'_m, rstd_m of (x_new - c_m) gathered in the same
+//     pass (gww_ln_fold_weights builds W', u, cb).  The LayerNorm kernel, its bf16 round
+//     trip, the second read of x and the residual read-modify-write of the GEMM epilogues
+//     all disappear.
 //   * only W moves through shared LDS: [128 n][64 k] tiles, global_load_lds (16 B/lane)
 //     into a 7-deep ring (a whole n-tile ahead, so epilogue stores never block the ring), counted vmcnt + one raw s_barrier per k-tile; W stays L2
 //     resident (<= 1.2 MB) and costs 16 KB per 1024 MFMA cycles per CU.
@@ -77,25 +83,23 @@ __device__ unsigned long long g_stamp[8];
 #endif
 
 // KT = K / 64 (k-tiles); A fragments: af[4 S + j] holds k = 64 S + 32 hh + 8 j .. +7 of row m.
-template <int EPI, int AMODE, int KT>
-__global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __restrict__ Aany, long lda,
-                                                       const unsigned short* __restrict__ delta,
-                                                       float* __restrict__ x_out,
-                                                       const float* __restrict__ ln_w,
-                                                       const float* __restrict__ ln_b,
+template <int EPI, int AMODE, int KT, bool HAS_DELTA>
+__global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* Aany, long lda,
+                                                       const unsigned short* delta,
+                                                       float* x_out,
+                                                       const float* __restrict__ ln_u,
+                                                       const float* __restrict__ ln_cb,
                                                        const unsigned short* __restrict__ W,
                                                        const float* __restrict__ bias, unsigned short* __restrict__ C,
                                                        long M, int N, int tiles_n, int n_split,
-                                                       int rows_per_batch, int valid_rows, long c_panel_rows,
-                                                       int dbg) {
+                                                       int rows_per_batch, int valid_rows, long c_panel_rows) {
   constexpr int K = KT * 64;
   constexpr int OFF_BIAS = AS_NST * AS_W_BYTES;
-  constexpr int OFF_LN = 0;                       // LayerNorm params live in the (not yet used) ring during the prologue
-  constexpr int OFF_SLICE = OFF_BIAS + 1536 * 4;
+  constexpr int OFF_U = OFF_BIAS + 1536 * 4;      // LN mode: column sums u[n] of the gain-folded weight
+  constexpr int OFF_SLICE = OFF_U + (AMODE == AMODE_LN ? 1536 * 4 : 0);
   __shared__ __attribute__((aligned(16))) unsigned char lds[OFF_SLICE + AS_WAVES * AS_SLICE_BYTES];
   float* lds_bias = reinterpret_cast<float*>(lds + OFF_BIAS);
-  float* lds_lnw = reinterpret_cast<float*>(lds + OFF_LN);
-  float* lds_lnb = lds_lnw + K;
+  float* lds_u = reinterpret_cast<float*>(lds + OFF_U);
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* g_ptr;
 
@@ -127,28 +131,25 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __rest
       __builtin_amdgcn_global_load_lds((g_ptr)(wb + w_off[j]), (lds_ptr)(sw + j * 1024), 16, 0, 0);
   };
 
-  for (int i = tid; i < (nt1 - nt0) * AS_BN; i += AS_THREADS) lds_bias[i] = bias ? bias[nt0 * AS_BN + i] : 0.f;
-  // De-phase the CUs: every workgroup of the first resident round starts (blockIdx % 8) * stagger
-  // later, so the HBM-read prologues, the L2-fed MFMA loops and the store epilogues of different
-  // CUs overlap in time instead of all CUs hammering the same resource in lock step.
-  if (dbg >> 8) {
-    const int steps = (blockIdx.x < 256) ? (blockIdx.x & 7) * (dbg >> 8) : 0;
-    for (int q = 0; q < steps; ++q) __builtin_amdgcn_s_sleep(127);   // ~3.4 us per step
+  if constexpr (AMODE == AMODE_LN) {
+    for (int i = tid; i < (nt1 - nt0) * AS_BN; i += AS_THREADS) {
+      lds_bias[i] = ln_cb[nt0 * AS_BN + i];
+      lds_u[i] = ln_u[nt0 * AS_BN + i];
+    }
+  } else {
+    for (int i = tid; i < (nt1 - nt0) * AS_BN; i += AS_THREADS) lds_bias[i] = bias ? bias[nt0 * AS_BN + i] : 0.f;
   }
-
   STAMP_DECL
   // ---- A fragments (whole K) for this wave's 32 rows
   bf16x8 af[KT * 4];
+  float row_rstd = 1.f, row_mean = 0.f;   // AMODE_LN: statistics of this lane's row m (accumulator layout)
   long grow[4];   // clamped global rows this lane touches in the coalesced passes
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long g = m_base + 8 * i + crow;
     grow[i] = g < M ? g : M - 1;
   }
-  if (dbg & 4) {   // tuning aid: no A loads
-#pragma unroll
-    for (int q = 0; q < KT * 4; ++q) af[q] = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
-  } else if constexpr (AMODE == AMODE_BF16) {
+  if constexpr (AMODE == AMODE_BF16) {
     const unsigned short* A = reinterpret_cast<const unsigned short*>(Aany);
 #pragma unroll
     for (int S = 0; S < KT; ++S) {
@@ -166,79 +167,83 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __rest
       }
     }
   } else {
-    // x_new = x (+ delta); LayerNorm (HF:modeling_whisper.py:392,402; eps 1e-5) -> bf16 fragments.
+    // x_new = x (+ delta) -> written back; operand a = bf16(x_new - c); exact fp32 statistics of
+    // (x_new - c) for the algebraic LayerNorm (HF:modeling_whisper.py:392,402; eps 1e-5).
     // Lane (crow, cchunk) owns float4 #cchunk of a 32-float half slice of rows 8 i + crow.
     const float* X = reinterpret_cast<const float*>(Aany);
-    for (int i = tid; i < K; i += AS_THREADS) {
-      lds_lnw[i] = ln_w[i];
-      lds_lnb[i] = ln_b[i];
-    }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool write_back = (x_out != nullptr) && split == 0;
-    auto load4 = [&](int i, int hs) -> float4 {
-      const long off = grow[i] * lda + 32 * hs + 4 * cchunk;
-      float4 v = *reinterpret_cast<const float4*>(X + off);
-      if (delta) {
-        const u32x2 dv = *reinterpret_cast<const u32x2*>(delta + off);
-        v.x += bf2f((unsigned short)(dv[0] & 0xffff));
-        v.y += bf2f((unsigned short)(dv[0] >> 16));
-        v.z += bf2f((unsigned short)(dv[1] & 0xffff));
-        v.w += bf2f((unsigned short)(dv[1] >> 16));
-      }
-      return v;
-    };
-#pragma unroll 6
-    for (int hs = 0; hs < 2 * KT; ++hs) {
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, cshift[4];
+    const unsigned short* D = delta;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 v = load4(i, hs);
-        if (write_back && m_base + 8 * i + crow < M)
-          *reinterpret_cast<float4*>(x_out + grow[i] * lda + 32 * hs + 4 * cchunk) = v;
-        s1[i] += (v.x + v.y) + (v.z + v.w);
-        s2[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    for (int S = 0; S < KT; ++S) {
+      // one k-tile (two 32-float half slices) per group: all 8 (+8) loads are issued back to back
+      // (branch-free: HAS_DELTA is a template flag), then consumed
+      __builtin_amdgcn_sched_barrier(0);
+      float4 xv[2][4];
+      u32x2 dv[2][4];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const long off = grow[i] * lda + 64 * S + 32 * h2 + 4 * cchunk;
+          xv[h2][i] = *reinterpret_cast<const float4*>(X + off);
+          if constexpr (HAS_DELTA) dv[h2][i] = *reinterpret_cast<const u32x2*>(D + off);
+        }
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float4 v = xv[h2][i];
+          if constexpr (HAS_DELTA) {
+            v.x += bf2f((unsigned short)(dv[h2][i][0] & 0xffff));
+            v.y += bf2f((unsigned short)(dv[h2][i][0] >> 16));
+            v.z += bf2f((unsigned short)(dv[h2][i][1] & 0xffff));
+            v.w += bf2f((unsigned short)(dv[h2][i][1] >> 16));
+            // x_new written back (rows past M are clamped duplicates of row M-1: same value, benign)
+            *reinterpret_cast<float4*>(x_out + grow[i] * lda + 64 * S + 32 * h2 + 4 * cchunk) = v;
+          }
+          if (S == 0 && h2 == 0) {   // shift = mean of the row's first 32 values (any shift is exact algebra)
+            float t = (v.x + v.y) + (v.z + v.w);
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            cshift[i] = t * (1.0f / 32.0f);
+          }
+          v.x -= cshift[i]; v.y -= cshift[i]; v.z -= cshift[i]; v.w -= cshift[i];
+          s1[i] += (v.x + v.y) + (v.z + v.w);
+          s2[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          u32x2 o = {pack2bf(v.x, v.y), pack2bf(v.z, v.w)};
+          *reinterpret_cast<u32x2*>(slice + (8 * i + crow) * AS_SLICE_STRIDE + h2 * 64 + cchunk * 8) = o;
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32x4 u = *reinterpret_cast<const u32x4*>(slice + r * AS_SLICE_STRIDE + (4 * hh + j) * 16);
+        asm volatile("" : "+v"(u)::"memory");
+        af[4 * S + j] = __builtin_bit_cast(bf16x8, u);
       }
     }
     STAMP(0);
-    float mean[4], rstd[4];
+    // row statistics -> the lanes that own the row in the accumulator layout (via the slice memory)
+    float* stat = reinterpret_cast<float*>(slice);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float a = s1[i], b = s2[i];
       a += __shfl_xor(a, 1, 64); b += __shfl_xor(b, 1, 64);
       a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64);
       a += __shfl_xor(a, 4, 64); b += __shfl_xor(b, 4, 64);
-      mean[i] = a * (1.0f / K);
-      const float var = fmaxf(b * (1.0f / K) - mean[i] * mean[i], 0.f);
-      rstd[i] = rsqrtf(var + 1e-5f);
-    }
-    asm volatile("" ::: "memory");   // second pass re-reads the rows (L2 hot) instead of holding 192 floats
-    __syncthreads();                 // LN params staged (no LDS-DMA in flight yet)
-#pragma unroll
-    for (int hs = 0; hs < 2 * KT; ++hs) {
-      if ((hs & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // <= 4 half slices (64 fp32) in flight per lane
-      const float4 g = *reinterpret_cast<const float4*>(lds_lnw + 32 * hs + 4 * cchunk);
-      const float4 bb = *reinterpret_cast<const float4*>(lds_lnb + 32 * hs + 4 * cchunk);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 v = load4(i, hs);
-        u32x2 o = {pack2bf((v.x - mean[i]) * rstd[i] * g.x + bb.x, (v.y - mean[i]) * rstd[i] * g.y + bb.y),
-                   pack2bf((v.z - mean[i]) * rstd[i] * g.z + bb.z, (v.w - mean[i]) * rstd[i] * g.w + bb.w)};
-        *reinterpret_cast<u32x2*>(slice + (8 * i + crow) * AS_SLICE_STRIDE + (hs & 1) * 64 + cchunk * 8) = o;
-      }
-      if (hs & 1) {
-        const int S = hs >> 1;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          u32x4 u = *reinterpret_cast<const u32x4*>(slice + r * AS_SLICE_STRIDE + (4 * hh + j) * 16);
-          asm volatile("" : "+v"(u)::"memory");
-          af[4 * S + j] = __builtin_bit_cast(bf16x8, u);
-        }
+      const float mean = a * (1.0f / K);
+      const float var = fmaxf(b * (1.0f / K) - mean * mean, 0.f);
+      if (cchunk == 0) {
+        stat[8 * i + crow] = rsqrtf(var + 1e-5f);
+        stat[32 + 8 * i + crow] = mean;
       }
     }
+    row_rstd = stat[r];
+    row_mean = stat[32 + r];
+    asm volatile("" : "+v"(row_rstd), "+v"(row_mean)::"memory");
   }
   // every ordinary load / store above is retired before the LDS-DMA ring starts counting
   as_wait_vmcnt<0>();
   STAMP(1);
-  if constexpr (AMODE == AMODE_LN) __syncthreads();   // LN params (aliased onto the ring) no longer needed
 #pragma unroll
   for (int p = 0; p < AS_D; ++p)
     if (p < total) issue(p);
@@ -269,7 +274,6 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __rest
       STAMP(2);
       if (it + AS_D < total) issue(it + AS_D);
       const unsigned char* Ws = lds + (it % AS_NST) * AS_W_BYTES;
-      if (dbg & 2) continue;   // tuning aid: ring only
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         bf16x8 wf[4];
@@ -283,12 +287,6 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __rest
     }
     // ---- epilogue: bias (+GELU) -> bf16 -> wave-private LDS transpose -> whole-line stores
     const int nn = nt0 + nti;
-    if (dbg & 1) {   // tuning aid: no epilogue (keep the accumulators alive)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(acc[t]));
-      if (dbg & 8) continue;
-    }
-    if (!(dbg & 1))
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -296,10 +294,16 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* __rest
         const int t = 2 * half + tt;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+          if ((c & 1) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the bias / u LDS reads from piling up in VGPRs
           const int nl = 32 * t + 8 * c + 4 * hh;
           const float4 bv = *reinterpret_cast<const float4*>(lds_bias + nti * AS_BN + nl);
-          float v0 = acc[t][4 * c] + bv.x, v1 = acc[t][4 * c + 1] + bv.y, v2 = acc[t][4 * c + 2] + bv.z,
-                v3 = acc[t][4 * c + 3] + bv.w;
+          float v0 = acc[t][4 * c], v1 = acc[t][4 * c + 1], v2 = acc[t][4 * c + 2], v3 = acc[t][4 * c + 3];
+          if constexpr (AMODE == AMODE_LN) {   // LayerNorm applied algebraically (see header)
+            const float4 uv = *reinterpret_cast<const float4*>(lds_u + nti * AS_BN + nl);
+            v0 = row_rstd * (v0 - row_mean * uv.x); v1 = row_rstd * (v1 - row_mean * uv.y);
+            v2 = row_rstd * (v2 - row_mean * uv.z); v3 = row_rstd * (v3 - row_mean * uv.w);
+          }
+          v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
           if constexpr (EPI == EPI_GELU || EPI == EPI_CONV1) {
             v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3);
           }
@@ -337,11 +341,12 @@ static int as_pick_split(long panels, int tiles_n) {
   return s;
 }
 
-// bf16 A [M, lda]                                     (ln_w == nullptr), or
-// fp32 residual stream x [M, lda] (+ bf16 delta [M, lda], x_out written back) with fused LayerNorm.
+// bf16 A [M, lda]                                     (ln_u == nullptr), or
+// fp32 residual stream x [M, lda] (+ bf16 delta [M, lda], x_out written back) with fused LayerNorm:
+// then W must be the gain-folded panel and ln_u / ln_cb the vectors built by gww_ln_fold_weights.
 // C is bf16 [>= roundup(M,256) (+1 for conv1), N]: whole 256-row panels are stored unconditionally.
-int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, const float* ln_w,
-                      const float* ln_b, const void* W, const float* bias, void* C, long M, int N, int K,
+int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, const float* ln_u,
+                      const float* ln_cb, const void* W, const float* bias, void* C, long M, int N, int K,
                       int epi, int rows_per_batch, hipStream_t s, long c_panel_rows) {
   GWW_REQUIRE(A && W && C, "gemm_astat: NULL operand");
   GWW_REQUIRE(K == 256 || K == 384 || K == 512, "gemm_astat: K=%d unsupported", K);
@@ -361,20 +366,27 @@ int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, 
   } else {
     rows_per_batch = 1;
   }
-  static const int dbg = getenv("GWW_ASTAT_DBG") ? atoi(getenv("GWW_ASTAT_DBG")) : 0;   // tuning aid
-  const bool ln = ln_w != nullptr;
+  const bool ln = ln_u != nullptr;
+  GWW_REQUIRE(!ln || ln_cb, "gemm_astat: ln_u and ln_cb go together");
   GWW_REQUIRE(ln || (!delta && !x_out), "gemm_astat: delta / x_out need the LayerNorm prologue");
   GWW_REQUIRE(!ln || lda == K, "gemm_astat: fused LayerNorm needs lda == K");
+  GWW_REQUIRE((delta == nullptr) == (x_out == nullptr), "gemm_astat: delta and x_out go together");
+  if (delta) n_split = 1;   // x_new is written back by exactly one workgroup per row panel
   dim3 grid((unsigned)(panels * n_split)), block(AS_THREADS);
-#define GWW_AS_LAUNCH(E, AM, KT)                                                                          \
-  hipLaunchKernelGGL((k_gemm_astat<E, AM, KT>), grid, block, 0, s, A, lda, (const unsigned short*)delta,  \
-                     x_out, ln_w, ln_b, (const unsigned short*)W, bias, (unsigned short*)C, M, N, tiles_n, \
-                     n_split, rows_per_batch, valid_rows, c_panel_rows, dbg)
-#define GWW_AS_K(E, AM)                         \
-  do {                                          \
-    if (K == 384) GWW_AS_LAUNCH(E, AM, 6);      \
-    else if (K == 512) GWW_AS_LAUNCH(E, AM, 8); \
-    else GWW_AS_LAUNCH(E, AM, 4);               \
+#define GWW_AS_LAUNCH(E, AM, KT, HD)                                                                        \
+  hipLaunchKernelGGL((k_gemm_astat<E, AM, KT, HD>), grid, block, 0, s, A, lda, (const unsigned short*)delta,  \
+                     x_out, ln_u, ln_cb, (const unsigned short*)W, bias, (unsigned short*)C, M, N, tiles_n, \
+                     n_split, rows_per_batch, valid_rows, c_panel_rows)
+#define GWW_AS_K2(E, AM, HD)                        \
+  do {                                              \
+    if (K == 384) GWW_AS_LAUNCH(E, AM, 6, HD);      \
+    else if (K == 512) GWW_AS_LAUNCH(E, AM, 8, HD); \
+    else GWW_AS_LAUNCH(E, AM, 4, HD);               \
+  } while (0)
+#define GWW_AS_K(E, AM)                              \
+  do {                                               \
+    if (AM == AMODE_LN && delta) GWW_AS_K2(E, AM, true); \
+    else GWW_AS_K2(E, AM, false);                    \
   } while (0)
   if (ln) {
     if (epi == EPI_BIAS) GWW_AS_K(EPI_BIAS, AMODE_LN);
@@ -387,6 +399,7 @@ int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, 
     else return fail(GWW_ERR_ARG, "gemm_astat: unsupported epilogue %d", epi);
   }
 #undef GWW_AS_K
+#undef GWW_AS_K2
 #undef GWW_AS_LAUNCH
   GWW_LAUNCH_CHECK();
   return GWW_OK;
@@ -396,13 +409,13 @@ int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, 
 
 using namespace gww;
 
-extern "C" int gww_gemm_astat_bf16(const void* A, const void* delta, float* x_out, const float* ln_w,
-                                   const float* ln_b, const void* W, const float* bias, void* C, long M, int N,
+extern "C" int gww_gemm_astat_bf16(const void* A, const void* delta, float* x_out, const float* ln_u,
+                                   const float* ln_cb, const void* W, const float* bias, void* C, long M, int N,
                                    int K, int epilogue, void* stream) {
   GWW_REQUIRE(epilogue == 0 || epilogue == 1, "gww_gemm_astat_bf16: epilogue must be 0 (bias) or 1 (GELU)");
-  GWW_REQUIRE((ln_w == nullptr) == (ln_b == nullptr), "gww_gemm_astat_bf16: ln_w and ln_b go together");
+  GWW_REQUIRE((ln_u == nullptr) == (ln_cb == nullptr), "gww_gemm_astat_bf16: ln_u and ln_cb go together");
   static const long dbg_panel = getenv("GWW_ASTAT_PANEL") ? atol(getenv("GWW_ASTAT_PANEL")) : 0;   // tuning aid
-  return launch_gemm_astat(A, K, delta, x_out, ln_w, ln_b, W, bias, C, M, N, K, epilogue, 0, (hipStream_t)stream,
+  return launch_gemm_astat(A, K, delta, x_out, ln_u, ln_cb, W, bias, C, M, N, K, epilogue, 0, (hipStream_t)stream,
                            dbg_panel ? (M + 255) / 256 * 256 : 0);
 }
 

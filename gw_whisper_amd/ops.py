@@ -102,31 +102,50 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, epi
     return c
 
 
-def gemm_astat(a: torch.Tensor, w: torch.Tensor, bias=None, epilogue: int = 0, ln_w=None, ln_b=None, delta=None,
+def ln_fold_weights(w: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, bias=None, scale: float = 1.0):
+    """Fold LayerNorm(gain ln_w, shift ln_b) into the Linear (w fp32 [N,K], bias) that follows it.
+    Returns (w_folded bf16 [N,K], u fp32 [N], cb fp32 [N]) for ``gemm_astat(..., ln=(u, cb))``."""
+    w = _dev(w, torch.float32, "w")
+    N, K = w.shape
+    wf = torch.empty((N, K), dtype=torch.bfloat16, device=w.device)
+    u = torch.empty((N,), dtype=torch.float32, device=w.device)
+    cb = torch.empty((N,), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        check(lib().gww_ln_fold_weights(w.data_ptr(), _dev(ln_w, torch.float32).data_ptr(),
+                                        _dev(ln_b, torch.float32).data_ptr(),
+                                        _dev(bias, torch.float32).data_ptr() if bias is not None else None,
+                                        float(scale), N, K, wf.data_ptr(), u.data_ptr(), cb.data_ptr(), _stream()),
+              "gww_ln_fold_weights")
+    return wf, u, cb
+
+
+def gemm_astat(a: torch.Tensor, w: torch.Tensor, bias=None, epilogue: int = 0, ln=None, delta=None,
                return_x: bool = False):
     """A-stationary bf16 GEMM (K in {256,384,512}) -> bf16 [M, N].
 
-    With ``ln_w``/``ln_b``, ``a`` is the fp32 residual stream: ``x_new = a + delta`` (bf16
-    ``delta`` optional) and LayerNorm are fused into the operand build; ``return_x`` also
-    returns ``x_new``.  Output rows are padded to a multiple of 256 internally."""
-    fused = ln_w is not None
+    ``ln=(u, cb)`` (from ``ln_fold_weights``, with ``w`` the folded panel): ``a`` is the fp32
+    residual stream, ``x_new = a + delta`` (bf16 ``delta`` optional) and LayerNorm are fused
+    into the GEMM in one pass; ``return_x`` also returns ``x_new``.  Output rows are padded
+    to a multiple of 256 internally."""
+    fused = ln is not None
     a = _dev(a, torch.float32 if fused else torch.bfloat16, "A")
     w = _dev(w, torch.bfloat16, "W")
     M, K = a.shape
     N = w.shape[0]
     Mp = (M + 255) // 256 * 256
     c = torch.empty((Mp, N), dtype=torch.bfloat16, device=a.device)
-    x_out = torch.empty_like(a) if (fused and return_x) else None
     dl = _dev(delta, torch.bfloat16, "delta") if delta is not None else None
+    # x_new is only materialised when there is a delta to add; otherwise x_new IS a
+    x_out = torch.empty_like(a) if (fused and return_x and dl is not None) else None
     with torch.cuda.device(a.device):
         check(lib().gww_gemm_astat_bf16(
-            a.data_ptr(), dl.data_ptr() if dl is not None else None,
+            a.data_ptr(), dl.data_ptr() if (dl is not None and x_out is not None) else None,
             x_out.data_ptr() if x_out is not None else None,
-            _dev(ln_w, torch.float32).data_ptr() if fused else None,
-            _dev(ln_b, torch.float32).data_ptr() if fused else None, w.data_ptr(),
+            _dev(ln[0], torch.float32).data_ptr() if fused else None,
+            _dev(ln[1], torch.float32).data_ptr() if fused else None, w.data_ptr(),
             _dev(bias, torch.float32).data_ptr() if bias is not None else None, c.data_ptr(), M, N, K,
             epilogue, _stream()), "gww_gemm_astat_bf16")
-    return (c[:M], x_out) if return_x else c[:M]
+    return (c[:M], x_out if x_out is not None else a) if return_x else c[:M]
 
 
 def gemm_fulln(a: torch.Tensor, w: torch.Tensor, bias=None, epilogue: int = 0) -> torch.Tensor:

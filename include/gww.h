@@ -140,16 +140,23 @@ int gww_gemm_bf16(const void* A, const void* W, const float* bias, const float* 
                   long M, int N, int K, int epilogue, void* stream);
 /* A-stationary bf16 GEMM for K in {256, 384, 512}, N % 128 == 0 (QKV / fc1 / out_proj at
  * whisper-tiny/base): C = epi(f(A) @ W^T + bias), C bf16, epilogue 0 (bias) or 1 (GELU).
- *   ln_w == NULL : A is bf16 [M,K].
- *   ln_w != NULL : A is the fp32 residual stream x [M,K]; the deferred residual add
- *                  x_new = x + delta (delta bf16 [M,K] or NULL) and LayerNorm (eps 1e-5,
- *                  HF:modeling_whisper.py:392,402) are fused into the operand build;
- *                  x_new is written to x_out (fp32 [M,K], may be NULL, must not alias A).
+ *   ln_u == NULL : A is bf16 [M,K], W the plain bf16 [N,K] panel.
+ *   ln_u != NULL : A is the fp32 residual stream x [M,K].  In ONE pass the kernel forms
+ *                  x_new = x + delta (delta bf16 [M,K] or NULL), writes it to x_out (fp32 [M,K],
+ *                  may be NULL, must not alias A) and applies LayerNorm (eps 1e-5,
+ *                  HF:modeling_whisper.py:392,402) algebraically: W must be the gain-folded
+ *                  panel and ln_u / ln_cb the vectors produced by gww_ln_fold_weights; `bias`
+ *                  is ignored (it is inside ln_cb).
  * Rows of C must be ALLOCATED up to the next multiple of 256: whole 256-row panels are stored
  * unconditionally (rows >= M are scratch). */
-int gww_gemm_astat_bf16(const void* A, const void* delta, float* x_out, const float* ln_w,
-                        const float* ln_b, const void* W, const float* bias, void* C, long M, int N,
+int gww_gemm_astat_bf16(const void* A, const void* delta, float* x_out, const float* ln_u,
+                        const float* ln_cb, const void* W, const float* bias, void* C, long M, int N,
                         int K, int epilogue, void* stream);
+/* Fold a LayerNorm into the Linear that follows it: w fp32 [N,K], ln_w / ln_b [K], bias [N] or NULL
+ *   w_folded[n][k] = bf16(scale * ln_w[k] * w[n][k]),   u[n] = sum_k w_folded[n][k],
+ *   cb[n] = scale * (bias[n] + sum_k ln_b[k] * w[n][k]). */
+int gww_ln_fold_weights(const float* w, const float* ln_w, const float* ln_b, const float* bias, float scale,
+                        int N, int K, void* w_folded_bf16, float* u, float* cb, void* stream);
 /* Full-N bf16 GEMM for the long-K, N = d contractions (fc2, conv2): one workgroup owns complete
  * 128-row x N output panels, so A is read from HBM once.  N in {384, 512}, K % 32 == 0, C bf16
  * [M,N] with rows allocated up to the next multiple of 128; epilogue 0 (bias) or 1 (GELU). */

@@ -23,14 +23,16 @@ h = x.bfloat16()
 dl = (torch.randn(M, d, device=dev) * 0.3).bfloat16()
 lw, lb = torch.ones(d, device=dev), torch.zeros(d, device=dev)
 cases = {
-    "ln+qkv": lambda: ops.gemm_astat(x, wqkv, bq, 0, ln_w=lw, ln_b=lb),
+    "ln+qkv": lambda: ops.gemm_astat(x, wq_f, None, 0, ln=(uq, cq)),
     "out": lambda: ops.gemm_astat(h, wo, bo, 0),
-    "resid+ln+fc1": lambda: ops.gemm_astat(x, w1, b1, 1, ln_w=lw, ln_b=lb, delta=dl, return_x=True),
+    "resid+ln+fc1": lambda: ops.gemm_astat(x, w1_f, None, 1, ln=(u1, c1), delta=dl, return_x=True),
 }
 wqkv = (torch.randn(3 * d, d, device=dev) / d ** 0.5).bfloat16(); bq = torch.randn(3 * d, device=dev)
 wo = (torch.randn(d, d, device=dev) / d ** 0.5).bfloat16(); bo = torch.randn(d, device=dev)
 w1 = (torch.randn(ffn, d, device=dev) / d ** 0.5).bfloat16(); b1 = torch.randn(ffn, device=dev)
-names = ["pass1(load+stats)", "pass2(normalise+frags)", "ring wait+barrier", "frag read + MFMA", "epilogue", "-"]
+wq_f, uq, cq = ops.ln_fold_weights(wqkv.float(), lw, lb, bq)
+w1_f, u1, c1 = ops.ln_fold_weights(w1.float(), lw, lb, b1)
+names = ["prologue pass (load/stats/frags)", "stats transfer + drain", "ring wait+barrier", "frag read + MFMA", "epilogue", "-"]
 for name, fn in cases.items():
     fn(); torch.cuda.synchronize()
     buf = (C.c_ulonglong * 8)()
