@@ -145,7 +145,8 @@ def main():
     ap.add_argument("--encoder", default="tiny")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true", help="skip the per-kernel event trace")
+    ap.add_argument("--isolated", action="store_true", help="also time each kernel class in isolation")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -184,15 +185,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace = not args.no_breakdown
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
+        if trace:
+            # hipEvents on the launch stream around every kernel of the TIMED steps (about 30 event
+            # records per forward, a few tens of microseconds per step)
+            enc.trace_enable(True)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
         barrier()
         dt = time.perf_counter() - t0
+        traced = enc.trace_read() if trace else {}
+        enc.trace_enable(False)
     assert torch.isfinite(out[1]).all()
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -220,19 +228,45 @@ def main():
                          "frac_of_hbm_peak": B * (64000 + 960000) / fe_ms / 1e6 / HBM_PEAK_GBS},
             "dora_step_ms": None,
         }
-        if not args.no_breakdown and args.precision == "bf16":
-            rows = kernel_breakdown(args.encoder, B, dev)
+        if traced:
+            M = B * T_TOK
+            es = 2 if args.precision == "bf16" else 4
+            # algorithmic FLOPs and HBM bytes of ONE launch of each kernel class
+            work = {
+                "mel_to_tokens": (0, B * (80 * T_IN * 4 + 80 * (T_IN + 2) * es)),
+                "conv1_gelu": (B * fl["conv1"], B * (T_IN + 2) * (80 + d) * es),
+                "conv2_gelu_pos": (B * fl["conv2"], B * ((T_IN + 2) * d * es + T_TOK * d * 4)),
+                "ln+qkv_proj": (B * 2 * T_TOK * d * 3 * d, M * (d * 4 + 3 * d * es)),
+                "attention": (B * fl["attn"], M * 4 * d * es),
+                "out_proj": (B * 2 * T_TOK * d * d, M * 2 * d * es),
+                "ln+fc1_gelu": (B * 2 * T_TOK * d * ffn, M * (d * 4 + ffn * es)),
+                "fc2": (B * 2 * T_TOK * d * ffn, M * (ffn + d) * es),
+                "final_layernorm": (0, M * d * 8),
+            }
+            rows = []
+            for name, (ms, cnt) in traced.items():
+                if cnt == 0:
+                    continue
+                per = ms / cnt
+                flops, byts = work[name]
+                rows.append({"kernel": name, "launches_per_step": cnt / args.steps, "ms_per_launch": per,
+                             "ms_per_step": ms / args.steps, "tflops": flops / per / 1e9 if flops else None,
+                             "algorithmic_gbs": byts / per / 1e6})
             line["kernels"] = rows
-            dom = max(rows, key=lambda r: r["ms"] * r["launches_per_fwd"])
+            dom = max(rows, key=lambda r: r["ms_per_step"])
             if dom["tflops"]:
                 line["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
                                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": dom["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                                    "ms_per_launch": dom["ms"]}
+                                    "ms_per_launch": dom["ms_per_launch"],
+                                    "share_of_step": dom["ms_per_step"] / ms_per_step}
             else:
-                line["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["gbs"],
-                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS,
-                                    "traffic": None, "ms_per_launch": dom["ms"]}
+                line["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["algorithmic_gbs"],
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["algorithmic_gbs"] / HBM_PEAK_GBS,
+                                    "traffic": None, "ms_per_launch": dom["ms_per_launch"],
+                                    "share_of_step": dom["ms_per_step"] / ms_per_step}
+        if args.isolated and args.precision == "bf16":
+            line["kernels_isolated"] = kernel_breakdown(args.encoder, B, dev)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.encoder)
         print(json.dumps(line), flush=True)

@@ -50,6 +50,10 @@ SIGNATURES = {
     "gww_encoder_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "gww_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gww_encoder_trace_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "gww_encoder_trace_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "gww_encoder_trace_classes": (C.c_int, []),
+    "gww_encoder_trace_class_name": (C.c_char_p, [C.c_int]),
     "gww_dora_merge_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gww_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long,

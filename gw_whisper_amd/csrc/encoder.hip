@@ -44,9 +44,17 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 }  // namespace
 
+// kernel classes of one forward, for the optional per-kernel event trace (bench.py roofline)
+enum : int { TR_MEL = 0, TR_CONV1, TR_CONV2, TR_QKV, TR_ATTN, TR_OUT, TR_FC1, TR_FC2, TR_LN, TR_COUNT };
+
+struct TraceSpan { int cls; hipEvent_t a, b; };
+
 struct gww_encoder {
   gww_enc_cfg cfg{};
   bool ready = false;
+  bool trace = false;
+  std::vector<TraceSpan> spans;     // recorded since the last read
+  std::vector<hipEvent_t> pool;     // reusable events
   char* blob = nullptr;
   size_t blob_bytes = 0;
   unsigned short *c1w = nullptr, *c2w = nullptr;
@@ -147,8 +155,41 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
   return GWW_OK;
 }
 
+extern "C" int gww_encoder_trace_enable(gww_encoder* e, int on) {
+  GWW_REQUIRE(e != nullptr, "gww_encoder_trace_enable: NULL handle");
+  e->trace = on != 0;
+  return GWW_OK;
+}
+
+// Sum the elapsed time (ms) and the launch count per kernel class since the last read; blocks until
+// the recorded events have completed.  ms / counts: arrays of gww_encoder_trace_classes() entries.
+extern "C" int gww_encoder_trace_read(gww_encoder* e, float* ms, int* counts) {
+  GWW_REQUIRE(e && ms && counts, "gww_encoder_trace_read: NULL argument");
+  for (int i = 0; i < TR_COUNT; ++i) { ms[i] = 0.f; counts[i] = 0; }
+  for (TraceSpan& sp : e->spans) {
+    GWW_HIP(hipEventSynchronize(sp.b));
+    float t = 0.f;
+    GWW_HIP(hipEventElapsedTime(&t, sp.a, sp.b));
+    ms[sp.cls] += t;
+    counts[sp.cls] += 1;
+    e->pool.push_back(sp.a);
+    e->pool.push_back(sp.b);
+  }
+  e->spans.clear();
+  return GWW_OK;
+}
+
+extern "C" int gww_encoder_trace_classes(void) { return TR_COUNT; }
+extern "C" const char* gww_encoder_trace_class_name(int i) {
+  static const char* names[TR_COUNT] = {"mel_to_tokens", "conv1_gelu", "conv2_gelu_pos", "ln+qkv_proj", "attention",
+                                        "out_proj", "ln+fc1_gelu", "fc2", "final_layernorm"};
+  return (i >= 0 && i < TR_COUNT) ? names[i] : "?";
+}
+
 extern "C" void gww_encoder_destroy(gww_encoder* e) {
   if (!e) return;
+  for (TraceSpan& sp : e->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+  for (hipEvent_t ev : e->pool) (void)hipEventDestroy(ev);
   if (e->blob) (void)hipFree(e->blob);
   delete e;
 }
@@ -279,6 +320,30 @@ extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, 
   void* f1 = base + w.f1;
   const long M = (long)B * T;
 
+  // optional per-kernel event trace: TR(cls, launch-expression)
+  auto tr_begin = [&](int cls) -> int {
+    if (!e->trace) return GWW_OK;
+    TraceSpan sp{cls, nullptr, nullptr};
+    for (hipEvent_t* ev : {&sp.a, &sp.b}) {
+      if (!e->pool.empty()) { *ev = e->pool.back(); e->pool.pop_back(); }
+      else GWW_HIP(hipEventCreate(ev));
+    }
+    GWW_HIP(hipEventRecord(sp.a, s));
+    e->spans.push_back(sp);
+    return GWW_OK;
+  };
+  auto tr_end = [&]() -> int {
+    if (!e->trace) return GWW_OK;
+    GWW_HIP(hipEventRecord(e->spans.back().b, s));
+    return GWW_OK;
+  };
+#define TR(cls, expr)        \
+  do {                       \
+    GWW_TRY(tr_begin(cls));  \
+    GWW_TRY(expr);           \
+    GWW_TRY(tr_end());       \
+  } while (0)
+
   // generic GEMM dispatch on precision
   auto gemm = [&](const void* A, long lda, const void* W16, const float* W32, const float* bias,
                   const float* resid, const float* pos, void* Cout, long Mr, int N, int K, int epi,
@@ -288,22 +353,22 @@ extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, 
   };
 
   // ---- stem
-  GWW_TRY(launch_mel_to_tokens(mel, melT, bf ? 1 : 0, B, C, Tin, s));
+  TR(TR_MEL, launch_mel_to_tokens(mel, melT, bf ? 1 : 0, B, C, Tin, s));
   GWW_HIP(hipMemsetAsync((char*)melT + (size_t)B * (Tin + 2) * C * es, 0, kConv1Kpad * es, s));
   GWW_HIP(hipMemsetAsync(c1, 0, (size_t)d * es, s));   // zero row 0 of batch 0 (token -1)
   // A-stationary kernels (A panel in registers, fused residual-add + LayerNorm prologue) for K = d <= 512
   const bool astat = bf && (d == 384 || d == 512) && F % 128 == 0;
   if (bf && d % 128 == 0)
-    GWW_TRY(launch_gemm_astat(melT, C, nullptr, nullptr, nullptr, nullptr, e->c1w, e->c1b, c1,
-                              (long)B * (Tin + 2), d, kConv1Kpad, EPI_CONV1, Tin + 2, s));
+    TR(TR_CONV1, launch_gemm_astat(melT, C, nullptr, nullptr, nullptr, nullptr, e->c1w, e->c1b, c1,
+                                   (long)B * (Tin + 2), d, kConv1Kpad, EPI_CONV1, Tin + 2, s));
   else
-    GWW_TRY(gemm(melT, C, e->c1w, e->c1w32, e->c1b, nullptr, nullptr, c1, (long)B * (Tin + 2), d, kConv1Kpad,
-                 EPI_CONV1, Tin + 2));
+    TR(TR_CONV1, gemm(melT, C, e->c1w, e->c1w32, e->c1b, nullptr, nullptr, c1, (long)B * (Tin + 2), d, kConv1Kpad,
+                      EPI_CONV1, Tin + 2));
   if (bf && (d == 384 || d == 512))
-    GWW_TRY(launch_gemm_fulln(c1, 2L * d, e->c2w, e->c2b, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2, T + 1, s));
+    TR(TR_CONV2, launch_gemm_fulln(c1, 2L * d, e->c2w, e->c2b, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2, T + 1, s));
   else
-    GWW_TRY(gemm(c1, 2L * d, e->c2w, e->c2w32, e->c2b, nullptr, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2,
-                 T + 1));
+    TR(TR_CONV2, gemm(c1, 2L * d, e->c2w, e->c2w32, e->c2b, nullptr, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2,
+                      T + 1));
   float* xc = x;                       // current residual stream
   const void* pending = nullptr;       // bf16 delta not yet added to xc (A-stationary path)
   if (astat) {
@@ -314,34 +379,35 @@ extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, 
     void* d2 = base + w.d2;
     for (int i = 0; i < e->cfg.n_layers; ++i) {
       const LayerW& L = e->layers[i];
-      GWW_TRY(launch_gemm_astat(xc, d, pending, pending ? xn : nullptr, L.uqkv, L.cbqkv, L.wqkv_ln, nullptr, qkv, M,
-                                3 * d, d, EPI_BIAS, 0, s));
+      TR(TR_QKV, launch_gemm_astat(xc, d, pending, pending ? xn : nullptr, L.uqkv, L.cbqkv, L.wqkv_ln, nullptr, qkv, M,
+                                   3 * d, d, EPI_BIAS, 0, s));
       if (pending) { float* t = xc; xc = xn; xn = t; }
-      GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s));
-      GWW_TRY(launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, L.wo, L.bo, d1, M, d, d, EPI_BIAS, 0, s));
-      GWW_TRY(launch_gemm_astat(xc, d, d1, xn, L.u1, L.cb1, L.w1_ln, nullptr, f1, M, F, d, EPI_GELU, 0, s));
+      TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s));
+      TR(TR_OUT, launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, L.wo, L.bo, d1, M, d, d, EPI_BIAS, 0, s));
+      TR(TR_FC1, launch_gemm_astat(xc, d, d1, xn, L.u1, L.cb1, L.w1_ln, nullptr, f1, M, F, d, EPI_GELU, 0, s));
       { float* t = xc; xc = xn; xn = t; }
-      GWW_TRY(launch_gemm_fulln(f1, F, L.w2, L.b2, nullptr, d2, M, d, F, EPI_BIAS, 0, s));
+      TR(TR_FC2, launch_gemm_fulln(f1, F, L.w2, L.b2, nullptr, d2, M, d, F, EPI_BIAS, 0, s));
       pending = d2;
     }
   } else {
     for (int i = 0; i < e->cfg.n_layers; ++i) {
       const LayerW& L = e->layers[i];
-      GWW_TRY(launch_layernorm(x, L.ln1w, L.ln1b, h, bf ? 1 : 0, M, d, s));
-      GWW_TRY(gemm(h, d, L.wqkv, L.wqkv32, L.bqkv, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0));
-      if (bf) GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s));
-      else GWW_TRY(launch_attention_f32((const float*)qkv, (float*)ctx, B, T, H, s));
-      GWW_TRY(gemm(ctx, d, L.wo, L.wo32, L.bo, x, nullptr, x, M, d, d, EPI_RESID, 0));
-      GWW_TRY(launch_layernorm(x, L.ln2w, L.ln2b, h, bf ? 1 : 0, M, d, s));
-      GWW_TRY(gemm(h, d, L.w1, L.w132, L.b1, nullptr, nullptr, f1, M, F, d, EPI_GELU, 0));
-      GWW_TRY(gemm(f1, F, L.w2, L.w232, L.b2, x, nullptr, x, M, d, F, EPI_RESID, 0));
+      TR(TR_LN, launch_layernorm(x, L.ln1w, L.ln1b, h, bf ? 1 : 0, M, d, s));
+      TR(TR_QKV, gemm(h, d, L.wqkv, L.wqkv32, L.bqkv, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0));
+      if (bf) TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s));
+      else TR(TR_ATTN, launch_attention_f32((const float*)qkv, (float*)ctx, B, T, H, s));
+      TR(TR_OUT, gemm(ctx, d, L.wo, L.wo32, L.bo, x, nullptr, x, M, d, d, EPI_RESID, 0));
+      TR(TR_LN, launch_layernorm(x, L.ln2w, L.ln2b, h, bf ? 1 : 0, M, d, s));
+      TR(TR_FC1, gemm(h, d, L.w1, L.w132, L.b1, nullptr, nullptr, f1, M, F, d, EPI_GELU, 0));
+      TR(TR_FC2, gemm(f1, F, L.w2, L.w232, L.b2, x, nullptr, x, M, d, F, EPI_RESID, 0));
     }
   }
   // ---- final LayerNorm (HF:modeling_whisper.py:642), with the last pending delta folded in;
   // callers pool token T-1 (Signal_vs_Noise/src/model.py:25-26): that row alone is a fast output
-  if (last_hidden) GWW_TRY(launch_layernorm(xc, e->lnw, e->lnb, last_hidden, 0, M, d, s, pending));
+  if (last_hidden) TR(TR_LN, launch_layernorm(xc, e->lnw, e->lnb, last_hidden, 0, M, d, s, pending));
   if (last_token)
-    GWW_TRY(launch_layernorm_rows(xc + (long)(T - 1) * d, (long)T * d, e->lnw, e->lnb, last_token, B, d, s,
-                                  pending ? (const char*)pending + (size_t)(T - 1) * d * 2 : nullptr));
+    TR(TR_LN, launch_layernorm_rows(xc + (long)(T - 1) * d, (long)T * d, e->lnw, e->lnb, last_token, B, d, s,
+                                    pending ? (const char*)pending + (size_t)(T - 1) * d * 2 : nullptr));
+#undef TR
   return GWW_OK;
 }

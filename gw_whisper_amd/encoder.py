@@ -213,6 +213,18 @@ class WhisperEncoder(nn.Module):
                                             torch.cuda.current_stream().cuda_stream), "gww_encoder_forward")
         return hidden, last
 
+    # ---- per-kernel event trace (bench.py roofline)
+    def trace_enable(self, on: bool = True):
+        check(lib().gww_encoder_trace_enable(self._ensure_handle(), int(on)), "gww_encoder_trace_enable")
+
+    def trace_read(self) -> dict:
+        """{kernel class: (total ms, launches)} since the last read (synchronises)."""
+        n = lib().gww_encoder_trace_classes()
+        ms = (C.c_float * n)()
+        cnt = (C.c_int * n)()
+        check(lib().gww_encoder_trace_read(self._ensure_handle(), ms, cnt), "gww_encoder_trace_read")
+        return {lib().gww_encoder_trace_class_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
+
     def forward(self, input_features, attention_mask=None, **kwargs):
         hidden, _ = self.forward_raw(input_features, want_hidden=True, want_last=False)
         return BaseModelOutput(last_hidden_state=hidden)

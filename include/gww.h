@@ -115,6 +115,15 @@ int gww_encoder_forward(gww_encoder* enc, const float* mel, int batch, int preci
                         void* workspace, size_t workspace_bytes,
                         float* last_hidden, float* last_token, void* stream);
 
+/* Optional per-kernel timing of the forward (hipEvents on the caller's stream around every
+ * launch; ~30 events per forward).  Classes: gww_encoder_trace_classes() entries named by
+ * gww_encoder_trace_class_name(i).  gww_encoder_trace_read sums elapsed ms and launch counts per
+ * class since the last read (it blocks until the recorded events completed). */
+int gww_encoder_trace_enable(gww_encoder* enc, int on);
+int gww_encoder_trace_read(gww_encoder* enc, float* ms, int* counts);
+int gww_encoder_trace_classes(void);
+const char* gww_encoder_trace_class_name(int i);
+
 /* --------------------------------------------------------------------------
  * DoRA.  Replaces peft's DoRA Linear (peft 0.12.0 tuners/lora/dora.py) created at
  *   Signal_vs_Noise/src/train.py:263-264 ; MLGWSC-1/train.py:695-696.
