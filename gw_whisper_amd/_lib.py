@@ -50,6 +50,7 @@ SIGNATURES = {
     "gww_encoder_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "gww_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gww_encoder_set_split": (C.c_int, [C.c_void_p, C.c_int]),
     "gww_encoder_trace_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "gww_encoder_trace_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "gww_encoder_trace_classes": (C.c_int, []),

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "epilogue.h"
 
+#include <stdlib.h>
 #include <vector>
 
 namespace gww {
@@ -55,6 +56,11 @@ struct gww_encoder {
   bool trace = false;
   std::vector<TraceSpan> spans;     // recorded since the last read
   std::vector<hipEvent_t> pool;     // reusable events
+  // dual-stream split: two half batches on two library-owned streams, so HBM-bound kernels of one
+  // half overlap MFMA-bound kernels of the other on different CUs
+  int split = 0;                    // 0: off, 1: on for batch >= 2 * kSplitMin
+  hipStream_t s2[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_skew = nullptr, ev_join[2] = {nullptr, nullptr};
   char* blob = nullptr;
   size_t blob_bytes = 0;
   unsigned short *c1w = nullptr, *c2w = nullptr;
@@ -190,6 +196,11 @@ extern "C" void gww_encoder_destroy(gww_encoder* e) {
   if (!e) return;
   for (TraceSpan& sp : e->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (hipEvent_t ev : e->pool) (void)hipEventDestroy(ev);
+  for (int i = 0; i < 2; ++i) {
+    if (e->s2[i]) (void)hipStreamDestroy(e->s2[i]);
+    if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
+  }
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->blob) (void)hipFree(e->blob);
   delete e;
 }
@@ -284,14 +295,36 @@ WsLayout ws_layout(const gww_enc_cfg& c, int B, int precision) {
 }
 }  // namespace
 
+constexpr int kSplitMin = 32;   // segments per half below which splitting does not pay
+
+static bool use_split(const gww_encoder* e, int batch) { return e->split && batch >= 2 * kSplitMin; }
+
 extern "C" size_t gww_encoder_workspace_bytes(const gww_encoder* e, int batch, int precision) {
   if (!e || batch <= 0) return 0;
+  if (use_split(e, batch)) {
+    const int b0 = batch / 2;
+    return ws_layout(e->cfg, b0, precision).total + ws_layout(e->cfg, batch - b0, precision).total;
+  }
   return ws_layout(e->cfg, batch, precision).total;
 }
 
-extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, int precision, void* workspace,
-                                   size_t workspace_bytes, float* last_hidden, float* last_token,
-                                   void* stream) {
+extern "C" int gww_encoder_set_split(gww_encoder* e, int on) {
+  GWW_REQUIRE(e != nullptr, "gww_encoder_set_split: NULL handle");
+  if (on && !e->s2[0]) {
+    for (int i = 0; i < 2; ++i) {
+      GWW_HIP(hipStreamCreateWithFlags(&e->s2[i], hipStreamNonBlocking));
+      GWW_HIP(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
+    }
+    GWW_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    GWW_HIP(hipEventCreateWithFlags(&e->ev_skew, hipEventDisableTiming));
+  }
+  e->split = on ? 1 : 0;
+  return GWW_OK;
+}
+
+static int forward_impl(gww_encoder* e, const float* mel, int batch, int precision, void* workspace,
+                        size_t workspace_bytes, float* last_hidden, float* last_token, void* stream,
+                        hipEvent_t skew_event = nullptr) {
   GWW_REQUIRE(e && mel, "gww_encoder_forward: NULL argument");
   if (!e->ready) return fail(GWW_ERR_STATE, "gww_encoder_forward: weights not set");
   GWW_REQUIRE(precision == GWW_PREC_BF16 || precision == GWW_PREC_F32, "gww_encoder_forward: bad precision %d",
@@ -382,6 +415,7 @@ extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, 
       TR(TR_QKV, launch_gemm_astat(xc, d, pending, pending ? xn : nullptr, L.uqkv, L.cbqkv, L.wqkv_ln, nullptr, qkv, M,
                                    3 * d, d, EPI_BIAS, 0, s));
       if (pending) { float* t = xc; xc = xn; xn = t; }
+      if (i == 0 && skew_event) GWW_HIP(hipEventRecord(skew_event, s));   // the other half batch starts here
       TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s));
       TR(TR_OUT, launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, L.wo, L.bo, d1, M, d, d, EPI_BIAS, 0, s));
       TR(TR_FC1, launch_gemm_astat(xc, d, d1, xn, L.u1, L.cb1, L.w1_ln, nullptr, f1, M, F, d, EPI_GELU, 0, s));
@@ -409,5 +443,38 @@ extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, 
     TR(TR_LN, launch_layernorm_rows(xc + (long)(T - 1) * d, (long)T * d, e->lnw, e->lnb, last_token, B, d, s,
                                     pending ? (const char*)pending + (size_t)(T - 1) * d * 2 : nullptr));
 #undef TR
+  return GWW_OK;
+}
+
+
+extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, int precision, void* workspace,
+                                   size_t workspace_bytes, float* last_hidden, float* last_token,
+                                   void* stream) {
+  GWW_REQUIRE(e && mel, "gww_encoder_forward: NULL argument");
+  if (batch <= 0 || !use_split(e, batch))
+    return forward_impl(e, mel, batch, precision, workspace, workspace_bytes, last_hidden, last_token, stream);
+  // two independent half batches on two streams, forked from / joined to the caller's stream
+  hipStream_t s = (hipStream_t)stream;
+  const int d = e->cfg.d_model, T = e->cfg.t_in / 2;
+  const int b[2] = {batch / 2, batch - batch / 2};
+  const size_t w0 = ws_layout(e->cfg, b[0], precision).total, w1 = ws_layout(e->cfg, b[1], precision).total;
+  if (!workspace || workspace_bytes < w0 + w1)
+    return fail(GWW_ERR_WORKSPACE, "gww_encoder_forward: workspace %zu bytes < required %zu", workspace_bytes, w0 + w1);
+  GWW_HIP(hipEventRecord(e->ev_fork, s));
+  int off = 0;
+  static const int skew = getenv("GWW_SPLIT_SKEW") ? atoi(getenv("GWW_SPLIT_SKEW")) : 0;   // tuning aid
+  for (int i = 0; i < 2; ++i) {
+    GWW_HIP(hipStreamWaitEvent(e->s2[i], e->ev_fork, 0));
+    if (i == 1 && skew) GWW_HIP(hipStreamWaitEvent(e->s2[1], e->ev_skew, 0));
+    const int rc = forward_impl(e, mel + (size_t)off * e->cfg.n_mels * e->cfg.t_in, b[i], precision,
+                                (char*)workspace + (i ? w0 : 0), i ? w1 : w0,
+                                last_hidden ? last_hidden + (size_t)off * T * d : nullptr,
+                                last_token ? last_token + (size_t)off * d : nullptr, e->s2[i],
+                                (i == 0 && skew) ? e->ev_skew : nullptr);
+    if (rc != GWW_OK) return rc;
+    GWW_HIP(hipEventRecord(e->ev_join[i], e->s2[i]));
+    GWW_HIP(hipStreamWaitEvent(s, e->ev_join[i], 0));
+    off += b[i];
+  }
   return GWW_OK;
 }

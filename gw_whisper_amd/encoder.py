@@ -213,6 +213,11 @@ class WhisperEncoder(nn.Module):
                                             torch.cuda.current_stream().cuda_stream), "gww_encoder_forward")
         return hidden, last
 
+    def set_split(self, on: bool = True):
+        """Process large batches as two half batches on two streams (see gww_encoder_set_split)."""
+        check(lib().gww_encoder_set_split(self._ensure_handle(), int(on)), "gww_encoder_set_split")
+        self._ws = None
+
     # ---- per-kernel event trace (bench.py roofline)
     def trace_enable(self, on: bool = True):
         check(lib().gww_encoder_trace_enable(self._ensure_handle(), int(on)), "gww_encoder_trace_enable")

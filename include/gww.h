@@ -115,6 +115,12 @@ int gww_encoder_forward(gww_encoder* enc, const float* mel, int batch, int preci
                         void* workspace, size_t workspace_bytes,
                         float* last_hidden, float* last_token, void* stream);
 
+/* Dual-stream split (off by default): batches of >= 64 segments are processed as two independent
+ * half batches on two library-owned streams forked from / joined to the caller's stream, so the
+ * HBM-bound kernels of one half overlap the MFMA-bound kernels of the other on different CUs.
+ * Changes gww_encoder_workspace_bytes; results are bit-identical (segments are independent). */
+int gww_encoder_set_split(gww_encoder* enc, int on);
+
 /* Optional per-kernel timing of the forward (hipEvents on the caller's stream around every
  * launch; ~30 events per forward).  Classes: gww_encoder_trace_classes() entries named by
  * gww_encoder_trace_class_name(i).  gww_encoder_trace_read sums elapsed ms and launch counts per

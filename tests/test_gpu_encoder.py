@@ -192,3 +192,18 @@ def test_two_channel_model_on_gpu_matches_reference_logits(T, gww, golden):
     assert np.abs(lg1 - g["one_channel_logits"]).max() < 1e-3
     np.testing.assert_array_equal(oheads.binary_labels(lg2), g["two_channel_labels"])
     np.testing.assert_array_equal(oheads.binary_labels(lg1), g["one_channel_labels"])
+
+
+def test_dual_stream_split_is_bit_identical(T, gww):
+    """gww_encoder_set_split: two half batches on two streams give exactly the single-stream result."""
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    sd = synth.encoder_state_dict(128, 2, 2, 512, seed=3)
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig(128, 2, 2, 512), precision="bf16").cuda()
+    g = T.Generator(device="cpu").manual_seed(1)
+    mel = (T.randn(70, 80, 3000, generator=g) * 0.5).cuda()
+    with T.no_grad():
+        a_h, a_l = enc.forward_raw(mel, want_hidden=True, want_last=True)
+        enc.set_split(True)
+        b_h, b_l = enc.forward_raw(mel, want_hidden=True, want_last=True)
+        T.cuda.synchronize()
+    assert T.equal(a_h, b_h) and T.equal(a_l, b_l)
