@@ -35,6 +35,12 @@ class EncLayer(C.Structure):
                  "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
 
 
+class DoraTarget(C.Structure):
+    _fields_ = [("layer", C.c_int), ("proj", C.c_int), ("r", C.c_int), ("scaling", C.c_float),
+                ("A", C.c_void_p), ("B", C.c_void_p), ("mag", C.c_void_p), ("nrm", C.c_void_p),
+                ("dA", C.c_void_p), ("dB", C.c_void_p), ("dm", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/gww.h declares
 SIGNATURES = {
     "gww_version": (C.c_int, []),
@@ -55,6 +61,21 @@ SIGNATURES = {
     "gww_encoder_trace_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "gww_encoder_trace_classes": (C.c_int, []),
     "gww_encoder_trace_class_name": (C.c_char_p, [C.c_int]),
+    "gww_train_saved_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "gww_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "gww_encoder_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                            C.c_size_t, C.c_void_p, C.c_void_p]),
+    "gww_encoder_train_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.POINTER(DoraTarget), C.c_int, C.c_void_p, C.c_void_p]),
+    "gww_attention_bwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gww_attention_lse_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gww_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_long, C.c_int, C.c_void_p]),
+    "gww_gelu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
+    "gww_dora_grads": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_float,
+                                 C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "gww_dora_merge_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gww_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long,

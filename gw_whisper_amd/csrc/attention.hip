@@ -38,7 +38,8 @@ __device__ __forceinline__ bf16x8 cvt8(const f32x16& a, int base) {
 }
 
 __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short* __restrict__ qkv,
-                                                           unsigned short* __restrict__ ctx, int T, int H,
+                                                           unsigned short* __restrict__ ctx,
+                                                           float* __restrict__ lse, int T, int H,
                                                            int q_tiles) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KB * DH * 2];   // 32 KB
   constexpr int TILE_BYTES = KB * DH * 2;
@@ -190,6 +191,8 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
+  // log-sum-exp of the row (training: the backward recomputes P = exp(S - LSE))
+  if (lse && q_row < T && hh == 0) lse[((long)b * H + h) * T + q_row] = m_run + __logf(l_tot);
   if (q_row < T) {
     unsigned short* orow = ctx + ((long)b * T + q_row) * d + h * DH;
 #pragma unroll
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
   }
 }
 
-int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipStream_t s) {
+int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipStream_t s, float* lse) {
   GWW_REQUIRE(qkv && ctx, "attention_bf16: NULL operand");
   GWW_REQUIRE(B >= 0 && T > 0 && H > 0, "attention_bf16: bad shape B=%d T=%d H=%d", B, T, H);
   GWW_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)ctx) & 15) == 0, "attention_bf16: 16-byte alignment");
@@ -213,7 +216,7 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
   const long blocks = (long)q_tiles * B * H;
   GWW_REQUIRE(blocks < 2147483647L, "attention_bf16: grid too large");
   hipLaunchKernelGGL(k_attention_bf16, dim3((unsigned)blocks), dim3(256), 0, s,
-                     (const unsigned short*)qkv, (unsigned short*)ctx, T, H, q_tiles);
+                     (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }
@@ -341,6 +344,10 @@ using namespace gww;
 
 extern "C" int gww_attention_bf16(const void* qkv, void* ctx, int B, int T, int n_heads, void* stream) {
   return launch_attention_bf16(qkv, ctx, B, T, n_heads, (hipStream_t)stream);
+}
+extern "C" int gww_attention_lse_bf16(const void* qkv, void* ctx, float* lse, int B, int T, int n_heads, void* stream) {
+  GWW_REQUIRE(lse != nullptr, "gww_attention_lse_bf16: lse is NULL");
+  return launch_attention_bf16(qkv, ctx, B, T, n_heads, (hipStream_t)stream, lse);
 }
 extern "C" int gww_attention_f32(const float* qkv, float* ctx, int B, int T, int n_heads, void* stream) {
   return launch_attention_f32(qkv, ctx, B, T, n_heads, (hipStream_t)stream);

@@ -1,0 +1,364 @@
+// Flash-style attention BACKWARD (for the DoRA training step): given dO, recompute
+// P = exp(S - LSE) from Q, K and the forward's log-sum-exp instead of storing the
+// 1500 x 1500 scores, and form
+//     D_i = sum_d dO_id O_id,  dP = dO V^T,  dS = P * (dP - D),
+//     dV = P^T dO,  dK = dS^T Q,  dQ = dS K          (q is pre-scaled, so no extra factor).
+// Layouts as the forward: qkv / dqkv [B, T, 3 d] (q | k | v), ctx / dctx [B, T, d], lse / D [B, H, T].
+//
+// Two kernels, no atomics (results are bitwise reproducible):
+//   k_attn_bwd_dq   one workgroup = 128 queries of one (b, h), loops over 64-key tiles
+//   k_attn_bwd_dkv  one workgroup = 128 keys of one (b, h), loops over 64-query tiles
+// Both reuse the forward's dataflow: the "swapped" 32x32x16 products keep the stationary index
+// (query resp. key) on the lane, the fp32 accumulator of the score-like products becomes, after a
+// pairwise bf16 conversion, the B operand of the following product (no LDS round trip), and the
+// transposed A operands come from row-major LDS tiles through ds_read_b64_tr_b16.  Tiles that are
+// read both by rows and transposed are kept as two LDS images (chunk-XOR resp. bit-6-XOR swizzle).
+#include "common.h"
+
+namespace gww {
+
+namespace {
+constexpr int DH = 64, TB = 128, KB = 64;
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr int TILE_BYTES = KB * DH * 2;   // 8 KB
+
+__device__ __forceinline__ int row_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int tr_off(int row, int colbyte) { return row * 128 + (colbyte ^ (((row >> 1) & 1) << 6)); }
+
+__device__ __forceinline__ bf16x8 cvt8(const f32x16& a, int base) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[base + j];
+  return r;
+}
+
+// transposed A operand (32x32x16): rows r0 + {4 hh + (j&3) + 8 (j>>2)} of a row-major [64][64] bf16 tile,
+// column 32 n + (lane & 31)
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int row0, int n, int lane) {
+  typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+  const int hh = lane >> 5;
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+  const int cb = 64 * n + (((lane & 31) >> 4) * 16 + 4 * tr_p) * 2;
+  const int r = row0 + 4 * hh + tr_q;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + tr_off(r, cb)));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + tr_off(r + 8, cb)));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+}  // namespace
+
+// D[b, h, t] = sum_d dO[b, t, h*64 + d] * O[b, t, h*64 + d]
+__global__ __launch_bounds__(256) void k_attn_rowdot(const unsigned short* __restrict__ o,
+                                                     const unsigned short* __restrict__ d_o,
+                                                     float* __restrict__ D, int T, int H, long rows) {
+  // one 8-lane group per (row, head): 8 lanes x 8 bf16 = 64
+  const long g = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  if (g >= rows * H) return;
+  const long row = g / H;
+  const int h = (int)(g - row * H);
+  const long off = row * (long)H * DH + h * DH + sub * 8;
+  const u32x4 a = *reinterpret_cast<const u32x4*>(o + off);
+  const u32x4 b = *reinterpret_cast<const u32x4*>(d_o + off);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s += bf2f((unsigned short)(a[j] & 0xffff)) * bf2f((unsigned short)(b[j] & 0xffff));
+    s += bf2f((unsigned short)(a[j] >> 16)) * bf2f((unsigned short)(b[j] >> 16));
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (sub == 0) {
+    const long bidx = row / T;
+    const int t = (int)(row - bidx * T);
+    D[(bidx * H + h) * T + t] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------ dQ
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const unsigned short* __restrict__ qkv,
+                                                        const unsigned short* __restrict__ dctx,
+                                                        const float* __restrict__ lse,
+                                                        const float* __restrict__ Dv,
+                                                        unsigned short* __restrict__ dqkv, int T, int H,
+                                                        int q_tiles) {
+  // per stage: K row image, K transposed-read image, V row image
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 3 * TILE_BYTES];   // 48 KB
+  auto Kr = [&](int buf) -> unsigned char* { return lds + (buf * 3 + 0) * TILE_BYTES; };
+  auto Kt = [&](int buf) -> unsigned char* { return lds + (buf * 3 + 1) * TILE_BYTES; };
+  auto Vr = [&](int buf) -> unsigned char* { return lds + (buf * 3 + 2) * TILE_BYTES; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = blockIdx.x % q_tiles, bh = blockIdx.x / q_tiles;
+  const int b = bh / H, h = bh - b * H, d = H * DH;
+  const long rs = 3L * d;
+  const unsigned short* base = qkv + (long)b * T * rs;
+  const unsigned short* qp = base + h * DH;
+  const unsigned short* kp = base + d + h * DH;
+  const unsigned short* vp = base + 2 * d + h * DH;
+  const int r = lane & 31, hh = lane >> 5;
+  const int q_row = qt * TB + wave * 32 + r;
+  const int q_ld = q_row < T ? q_row : T - 1;
+
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = *reinterpret_cast<const bf16x8*>(qp + (long)q_ld * rs + 16 * s + 8 * hh);
+    dof[s] = *reinterpret_cast<const bf16x8*>(dctx + ((long)b * T + q_ld) * d + h * DH + 16 * s + 8 * hh);
+  }
+  const float lse_q = lse[((long)b * H + h) * T + q_ld] * kLog2e;
+  const float D_q = Dv[((long)b * H + h) * T + q_ld];
+
+  int st_row[2], st_chunk[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    st_row[i] = c >> 3;
+    st_chunk[i] = c & 7;
+  }
+  u32x4 rk[2], rv[2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = kt * KB + st_row[i];
+      if (key >= T) key = T - 1;
+      rk[i] = *reinterpret_cast<const u32x4*>(kp + (long)key * rs + st_chunk[i] * 8);
+      rv[i] = *reinterpret_cast<const u32x4*>(vp + (long)key * rs + st_chunk[i] * 8);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<u32x4*>(Kr(buf) + row_off(st_row[i], st_chunk[i])) = rk[i];
+      *reinterpret_cast<u32x4*>(Kt(buf) + tr_off(st_row[i], st_chunk[i] * 16)) = rk[i];
+      *reinterpret_cast<u32x4*>(Vr(buf) + row_off(st_row[i], st_chunk[i])) = rv[i];
+    }
+  };
+
+  f32x16 dqt[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dqt[n][j] = 0.f;
+
+  const int n_kt = (T + KB - 1) / KB;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < n_kt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < n_kt) gload(kt + 1);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f32x16 st, dpt;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { st[j] = 0.f; dpt[j] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kr(buf) + row_off(32 * g + r, 2 * s + hh));
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vr(buf) + row_off(32 * g + r, 2 * s + hh));
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dpt, 0, 0, 0);
+      }
+      // dS^T = P^T * (dP^T - D), P^T = exp(S^T - LSE); keys >= T contribute nothing
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int key = kt * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        const float p = (key < T) ? __builtin_amdgcn_exp2f(fmaf(st[j], kLog2e, -lse_q)) : 0.f;
+        st[j] = p * (dpt[j] - D_q);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 dsf = cvt8(st, 8 * s);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          dqt[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt(buf), 32 * g + 16 * s, n, lane), dsf, dqt[n], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < n_kt) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  if (q_row < T) {
+    unsigned short* orow = dqkv + ((long)b * T + q_row) * rs + h * DH;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        u32x2 o = {pack2bf(dqt[n][4 * c], dqt[n][4 * c + 1]), pack2bf(dqt[n][4 * c + 2], dqt[n][4 * c + 3])};
+        *reinterpret_cast<u32x2*>(orow + 32 * n + 8 * c + 4 * hh) = o;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------ dK, dV
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* __restrict__ qkv,
+                                                         const unsigned short* __restrict__ dctx,
+                                                         const float* __restrict__ lse,
+                                                         const float* __restrict__ Dv,
+                                                         unsigned short* __restrict__ dqkv, int T, int H,
+                                                         int k_tiles) {
+  // per stage: Q row image, Q transposed-read image, dO row image, dO transposed-read image, lse[64], D[64]
+  constexpr int STAGE = 4 * TILE_BYTES + 512;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];   // 65 KB
+  auto Qr = [&](int buf) -> unsigned char* { return lds + buf * STAGE; };
+  auto Qt = [&](int buf) -> unsigned char* { return lds + buf * STAGE + TILE_BYTES; };
+  auto Or = [&](int buf) -> unsigned char* { return lds + buf * STAGE + 2 * TILE_BYTES; };
+  auto Ot = [&](int buf) -> unsigned char* { return lds + buf * STAGE + 3 * TILE_BYTES; };
+  auto Ls = [&](int buf) -> float* { return reinterpret_cast<float*>(lds + buf * STAGE + 4 * TILE_BYTES); };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ktile = blockIdx.x % k_tiles, bh = blockIdx.x / k_tiles;
+  const int b = bh / H, h = bh - b * H, d = H * DH;
+  const long rs = 3L * d;
+  const unsigned short* base = qkv + (long)b * T * rs;
+  const unsigned short* qp = base + h * DH;
+  const unsigned short* kp = base + d + h * DH;
+  const unsigned short* vp = base + 2 * d + h * DH;
+  const unsigned short* dop = dctx + (long)b * T * d + h * DH;
+  const float* lsep = lse + ((long)b * H + h) * T;
+  const float* Dp = Dv + ((long)b * H + h) * T;
+  const int r = lane & 31, hh = lane >> 5;
+  const int key_row = ktile * TB + wave * 32 + r;
+  const int key_ld = key_row < T ? key_row : T - 1;
+
+  bf16x8 kf[4], vf[4];   // B operands: K[key = r][dh = 16 s + 8 hh + j], V likewise
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = *reinterpret_cast<const bf16x8*>(kp + (long)key_ld * rs + 16 * s + 8 * hh);
+    vf[s] = *reinterpret_cast<const bf16x8*>(vp + (long)key_ld * rs + 16 * s + 8 * hh);
+  }
+
+  int st_row[2], st_chunk[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    st_row[i] = c >> 3;
+    st_chunk[i] = c & 7;
+  }
+  u32x4 rq[2], ro[2];
+  float rl = 0.f;
+  auto gload = [&](int qt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int q = qt * KB + st_row[i];
+      if (q >= T) q = T - 1;
+      rq[i] = *reinterpret_cast<const u32x4*>(qp + (long)q * rs + st_chunk[i] * 8);
+      ro[i] = *reinterpret_cast<const u32x4*>(dop + (long)q * d + st_chunk[i] * 8);
+    }
+    if (tid < 128) {
+      const int q = qt * KB + (tid & 63);
+      // queries past T get LSE = +inf (P = 0) and D = 0
+      rl = (tid < 64) ? (q < T ? lsep[q] * kLog2e : INFINITY) : (q < T ? Dp[q] : 0.f);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<u32x4*>(Qr(buf) + row_off(st_row[i], st_chunk[i])) = rq[i];
+      *reinterpret_cast<u32x4*>(Qt(buf) + tr_off(st_row[i], st_chunk[i] * 16)) = rq[i];
+      *reinterpret_cast<u32x4*>(Or(buf) + row_off(st_row[i], st_chunk[i])) = ro[i];
+      *reinterpret_cast<u32x4*>(Ot(buf) + tr_off(st_row[i], st_chunk[i] * 16)) = ro[i];
+    }
+    if (tid < 128) Ls(buf)[tid] = rl;   // [0,64): lse * log2e, [64,128): D
+  };
+
+  f32x16 dkt[2], dvt[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { dkt[n][j] = 0.f; dvt[n][j] = 0.f; }
+
+  const int n_qt = (T + KB - 1) / KB;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int qt = 0; qt < n_qt; ++qt) {
+    const int buf = qt & 1;
+    if (qt + 1 < n_qt) gload(qt + 1);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      // S[q][key], dP[q][key]: rows q = 32 g + (reg&3) + 8 (reg>>2) + 4 hh in registers, key on the lane
+      f32x16 sm, dpm;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { sm[j] = 0.f; dpm[j] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qr(buf) + row_off(32 * g + r, 2 * s + hh));
+        const bf16x8 oa = *reinterpret_cast<const bf16x8*>(Or(buf) + row_off(32 * g + r, 2 * s + hh));
+        sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], sm, 0, 0, 0);
+        dpm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[s], dpm, 0, 0, 0);
+      }
+      f32x16 ds;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 l4 = *reinterpret_cast<const float4*>(Ls(buf) + 32 * g + 8 * c + 4 * hh);
+        const float4 d4 = *reinterpret_cast<const float4*>(Ls(buf) + 64 + 32 * g + 8 * c + 4 * hh);
+        const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(sm[4 * c + e], kLog2e, -ll[e]));
+          sm[4 * c + e] = p;
+          ds[4 * c + e] = p * (dpm[4 * c + e] - dd[e]);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = cvt8(sm, 8 * s), dsf = cvt8(ds, 8 * s);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          dvt[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot(buf), 32 * g + 16 * s, n, lane), pf, dvt[n], 0, 0, 0);
+          dkt[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt(buf), 32 * g + 16 * s, n, lane), dsf, dkt[n], 0, 0, 0);
+        }
+      }
+    }
+    if (qt + 1 < n_qt) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  if (key_row < T) {
+    unsigned short* krow = dqkv + ((long)b * T + key_row) * rs + d + h * DH;
+    unsigned short* vrow = krow + d;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        u32x2 ok = {pack2bf(dkt[n][4 * c], dkt[n][4 * c + 1]), pack2bf(dkt[n][4 * c + 2], dkt[n][4 * c + 3])};
+        u32x2 ov = {pack2bf(dvt[n][4 * c], dvt[n][4 * c + 1]), pack2bf(dvt[n][4 * c + 2], dvt[n][4 * c + 3])};
+        *reinterpret_cast<u32x2*>(krow + 32 * n + 8 * c + 4 * hh) = ok;
+        *reinterpret_cast<u32x2*>(vrow + 32 * n + 8 * c + 4 * hh) = ov;
+      }
+  }
+}
+
+// qkv, ctx, dctx bf16; lse [B,H,T] from the forward; D [B,H,T] scratch; dqkv [B,T,3d] out
+int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* D,
+                              void* dqkv, int B, int T, int H, hipStream_t s) {
+  GWW_REQUIRE(qkv && ctx && dctx && lse && D && dqkv, "attention_bwd: NULL operand");
+  GWW_REQUIRE(B >= 0 && T > 0 && H > 0, "attention_bwd: bad shape");
+  if (B == 0) return GWW_OK;
+  const long rows = (long)B * T;
+  hipLaunchKernelGGL(k_attn_rowdot, dim3((unsigned)cdiv(rows * H * 8, 256)), dim3(256), 0, s,
+                     (const unsigned short*)ctx, (const unsigned short*)dctx, D, T, H, rows);
+  GWW_LAUNCH_CHECK();
+  const int tiles = (T + TB - 1) / TB;
+  const long blocks = (long)tiles * B * H;
+  GWW_REQUIRE(blocks < 2147483647L, "attention_bwd: grid too large");
+  hipLaunchKernelGGL(k_attn_bwd_dq, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)qkv,
+                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles);
+  GWW_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_attn_bwd_dkv, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)qkv,
+                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+}  // namespace gww
+
+using namespace gww;
+
+extern "C" int gww_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                                      float* d_scratch, void* dqkv, int B, int T, int n_heads, void* stream) {
+  return launch_attention_bwd_bf16(qkv, ctx, dctx, lse, d_scratch, dqkv, B, T, n_heads, (hipStream_t)stream);
+}

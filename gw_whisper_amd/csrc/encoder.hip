@@ -21,6 +21,15 @@
 #include <vector>
 
 namespace gww {
+int launch_transpose_bf16(const void* in, void* out, int R, int Cn, hipStream_t s);
+int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int dy_f32, float* dx, int accumulate,
+                  void* dx_bf16, long M, int d, hipStream_t s);
+int launch_gelu_bf16(const void* z, const void* df, void* out, long n, hipStream_t s);
+int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
+                      float yscale, float scaling, const float* A, const float* Bm, const float* mag,
+                      const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s);
+int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* D,
+                              void* dqkv, int B, int T, int H, hipStream_t s);
 int launch_mel_to_tokens(const float* mel, void* out, int out_bf16, int B, int C, int T, hipStream_t s);
 }
 
@@ -37,6 +46,8 @@ struct LayerW {
   // LayerNorm-folded panels for the A-stationary GEMMs (gain folded into W, see gemm_astat.hip)
   unsigned short *wqkv_ln, *w1_ln;
   float *uqkv, *cbqkv, *u1, *cb1;
+  // transposed bf16 panels [K][N] for the dX GEMMs of the training backward
+  unsigned short *wqkvT, *woT, *w1T, *w2T;
 };
 
 constexpr int kConv1Kpad = 256;   // 3 * 80 = 240 padded to a multiple of 64
@@ -89,7 +100,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
   const size_t o_c1b = take(d * 4), o_c2b = take(d * 4), o_pos = take((size_t)T * d * 4);
   const size_t o_lnw = take(d * 4), o_lnb = take(d * 4);
   struct LO { size_t wqkv, wo, w1, w2, wqkv32, wo32, w132, w232, bqkv, bo, b1, b2, ln1w, ln1b, ln2w, ln2b,
-                     wqkv_ln, w1_ln, uqkv, cbqkv, u1, cb1; };
+                     wqkv_ln, w1_ln, uqkv, cbqkv, u1, cb1, wqkvT, woT, w1T, w2T; };
   std::vector<LO> lo(L);
   for (int i = 0; i < L; ++i) {
     lo[i].wqkv = take((size_t)3 * d * d * 2);
@@ -114,6 +125,10 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
     lo[i].cbqkv = take(3 * d * 4);
     lo[i].u1 = take(F * 4);
     lo[i].cb1 = take(F * 4);
+    lo[i].wqkvT = take((size_t)3 * d * d * 2);
+    lo[i].woT = take((size_t)d * d * 2);
+    lo[i].w1T = take((size_t)F * d * 2);
+    lo[i].w2T = take((size_t)d * F * 2);
   }
   hipError_t err = hipMalloc(&e->blob, off);
   if (err != hipSuccess) {
@@ -156,6 +171,10 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
     w.cbqkv = (float*)(p + lo[i].cbqkv);
     w.u1 = (float*)(p + lo[i].u1);
     w.cb1 = (float*)(p + lo[i].cb1);
+    w.wqkvT = (unsigned short*)(p + lo[i].wqkvT);
+    w.woT = (unsigned short*)(p + lo[i].woT);
+    w.w1T = (unsigned short*)(p + lo[i].w1T);
+    w.w2T = (unsigned short*)(p + lo[i].w2T);
   }
   *out = e;
   return GWW_OK;
@@ -263,6 +282,11 @@ extern "C" int gww_encoder_set_weights(gww_encoder* e, const gww_enc_globals* g,
     GWW_TRY(launch_ln_fold(L.v_w, L.ln1_w, L.ln1_b, L.v_b, 1.f, d, d, w.wqkv_ln + 2 * dd, w.uqkv + 2 * d,
                            w.cbqkv + 2 * d, s));
     GWW_TRY(launch_ln_fold(L.fc1_w, L.ln2_w, L.ln2_b, L.fc1_b, 1.f, F, d, w.w1_ln, w.u1, w.cb1, s));
+    // transposed panels for the backward dX GEMMs:  [N][K] -> [K][N]
+    GWW_TRY(launch_transpose_bf16(w.wqkv, w.wqkvT, 3 * d, d, s));
+    GWW_TRY(launch_transpose_bf16(w.wo, w.woT, d, d, s));
+    GWW_TRY(launch_transpose_bf16(w.w1, w.w1T, F, d, s));
+    GWW_TRY(launch_transpose_bf16(w.w2, w.w2T, d, F, s));
   }
   e->ready = true;
   return GWW_OK;
@@ -476,5 +500,193 @@ extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, 
     GWW_HIP(hipStreamWaitEvent(s, e->ev_join[i], 0));
     off += b[i];
   }
+  return GWW_OK;
+}
+
+
+// =====================================================================================
+// DoRA training step (bf16): forward that keeps the activations the backward needs, and the
+// backward through the whole layer stack down to the residual stream entering layer 0.
+// Plain per-op path (LayerNorm kernel, generic GEMM with residual epilogue): the weights are
+// frozen, so there are no weight-gradient GEMMs -- only dX GEMMs against transposed panels,
+// the flash-attention backward and the rank-r DoRA parameter gradients.
+//
+// saved arena (caller-owned), per layer l:
+//   x_in[l] f32 [Mp,d] | h1 bf16 [Mp,d] | qkv bf16 [Mp,3d] | lse f32 [B,H,T] | ctx bf16 [Mp,d] |
+//   x_mid f32 [Mp,d] | z bf16 [Mp,ffn]                      and x_in[L] = input of the final LayerNorm
+namespace {
+struct SavedLayout {
+  size_t layer_stride, x_in, h1, qkv, lse, ctx, x_mid, z, total;
+};
+SavedLayout saved_layout(const gww_enc_cfg& c, int B) {
+  const size_t d = c.d_model, F = c.ffn, T = c.t_in / 2, H = c.n_heads;
+  const size_t Mp = ((size_t)B * T + 255) / 256 * 256 + 512;
+  SavedLayout s{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+  s.x_in = take(Mp * d * 4);
+  s.h1 = take(Mp * d * 2);
+  s.qkv = take(Mp * 3 * d * 2);
+  s.lse = take((size_t)B * H * T * 4);
+  s.ctx = take(Mp * d * 2);
+  s.x_mid = take(Mp * d * 4);
+  s.z = take(Mp * F * 2);
+  s.layer_stride = off;
+  s.total = off * c.n_layers + align_up(Mp * d * 4);   // + x_in[L]
+  return s;
+}
+struct TrainWs {
+  size_t melT, c1, h2, f1, dx, dxb, dbig, dh, dctx, dqkv, Dv, total;
+};
+TrainWs train_ws(const gww_enc_cfg& c, int B) {
+  const size_t d = c.d_model, F = c.ffn, Tin = c.t_in, T = c.t_in / 2, C = c.n_mels, H = c.n_heads;
+  const size_t Mp = ((size_t)B * T + 255) / 256 * 256 + 512;
+  TrainWs w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+  w.melT = take(((size_t)B * (Tin + 2) * C + kConv1Kpad) * 2);
+  w.c1 = take((((size_t)B * (Tin + 2) + 255) / 256 * 256 + 2) * d * 2);
+  w.h2 = take(Mp * d * 2);
+  w.f1 = take(Mp * F * 2);
+  w.dx = take(Mp * d * 4);
+  w.dxb = take(Mp * d * 2);
+  w.dbig = take(Mp * F * 2);
+  w.dh = take(Mp * d * 2);
+  w.dctx = take(Mp * d * 2);
+  w.dqkv = take(Mp * 3 * d * 2);
+  w.Dv = take((size_t)B * H * T * 4);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t gww_train_saved_bytes(const gww_encoder* e, int batch) {
+  return (e && batch > 0) ? saved_layout(e->cfg, batch).total : 0;
+}
+extern "C" size_t gww_train_workspace_bytes(const gww_encoder* e, int batch) {
+  return (e && batch > 0) ? train_ws(e->cfg, batch).total : 0;
+}
+
+extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int batch, void* workspace,
+                                         size_t workspace_bytes, void* saved, size_t saved_bytes,
+                                         float* last_hidden, void* stream) {
+  GWW_REQUIRE(e && mel && workspace && saved && last_hidden, "gww_encoder_train_forward: NULL argument");
+  if (!e->ready) return fail(GWW_ERR_STATE, "gww_encoder_train_forward: weights not set");
+  GWW_REQUIRE(batch > 0, "gww_encoder_train_forward: batch must be positive");
+  const SavedLayout sl = saved_layout(e->cfg, batch);
+  const TrainWs w = train_ws(e->cfg, batch);
+  if (workspace_bytes < w.total || saved_bytes < sl.total)
+    return fail(GWW_ERR_WORKSPACE, "gww_encoder_train_forward: workspace %zu / saved %zu bytes < required %zu / %zu",
+                workspace_bytes, saved_bytes, w.total, sl.total);
+  hipStream_t s = (hipStream_t)stream;
+  const int d = e->cfg.d_model, F = e->cfg.ffn, Tin = e->cfg.t_in, T = Tin / 2, C = e->cfg.n_mels, H = e->cfg.n_heads;
+  const int B = batch, L = e->cfg.n_layers;
+  const long M = (long)B * T;
+  char* base = (char*)workspace;
+  char* sv = (char*)saved;
+  void* melT = base + w.melT;
+  void* c1 = base + w.c1;
+  void* h2 = base + w.h2;
+  void* f1 = base + w.f1;
+  auto x_in = [&](int l) -> float* { return (float*)(sv + (l < L ? (size_t)l * sl.layer_stride + sl.x_in : (size_t)L * sl.layer_stride)); };
+  // ---- stem (same kernels as inference) -> x_in[0]
+  GWW_TRY(launch_mel_to_tokens(mel, melT, 1, B, C, Tin, s));
+  GWW_HIP(hipMemsetAsync((char*)melT + (size_t)B * (Tin + 2) * C * 2, 0, kConv1Kpad * 2, s));
+  GWW_HIP(hipMemsetAsync(c1, 0, (size_t)d * 2, s));
+  GWW_TRY(launch_gemm_bf16(melT, C, e->c1w, e->c1b, nullptr, nullptr, c1, (long)B * (Tin + 2), d, kConv1Kpad, EPI_CONV1,
+                           Tin + 2, s, 0));
+  GWW_TRY(launch_gemm_bf16(c1, 2L * d, e->c2w, e->c2b, nullptr, e->pos, x_in(0), (long)B * (T + 1), d, 3 * d, EPI_CONV2,
+                           T + 1, s, 1));
+  for (int l = 0; l < L; ++l) {
+    const LayerW& W = e->layers[l];
+    char* lb = sv + (size_t)l * sl.layer_stride;
+    void* h1 = lb + sl.h1;
+    void* qkv = lb + sl.qkv;
+    float* lse = (float*)(lb + sl.lse);
+    void* ctx = lb + sl.ctx;
+    float* x_mid = (float*)(lb + sl.x_mid);
+    void* z = lb + sl.z;
+    GWW_TRY(launch_layernorm(x_in(l), W.ln1w, W.ln1b, h1, 1, M, d, s));
+    GWW_TRY(launch_gemm_bf16(h1, d, W.wqkv, W.bqkv, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0, s, 1));
+    GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s, lse));
+    GWW_TRY(launch_gemm_bf16(ctx, d, W.wo, W.bo, x_in(l), nullptr, x_mid, M, d, d, EPI_RESID, 0, s, 1));
+    GWW_TRY(launch_layernorm(x_mid, W.ln2w, W.ln2b, h2, 1, M, d, s));
+    GWW_TRY(launch_gemm_bf16(h2, d, W.w1, W.b1, nullptr, nullptr, z, M, F, d, EPI_BIAS, 0, s, 1));
+    GWW_TRY(launch_gelu_bf16(z, nullptr, f1, ((M * F + 7) / 8) * 8, s));
+    GWW_TRY(launch_gemm_bf16(f1, F, W.w2, W.b2, x_mid, nullptr, x_in(l + 1), M, d, F, EPI_RESID, 0, s, 1));
+  }
+  GWW_TRY(launch_layernorm(x_in(L), e->lnw, e->lnb, last_hidden, 0, M, d, s));
+  return GWW_OK;
+}
+
+// d_last_hidden: fp32 [B*T, d] gradient of the loss w.r.t. last_hidden_state.
+// targets: DoRA-adapted projections whose A / B / magnitude gradients are wanted; the gradient buffers
+// are ACCUMULATED into (zero them once per step).  d_x0 (optional, fp32 [B*T, d]): gradient w.r.t. the
+// residual stream entering layer 0 (the conv stem output).
+extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* workspace, size_t workspace_bytes,
+                                          const void* saved, size_t saved_bytes, const float* d_last_hidden,
+                                          const gww_dora_target* targets, int n_targets, float* d_x0,
+                                          void* stream) {
+  GWW_REQUIRE(e && workspace && saved && d_last_hidden, "gww_encoder_train_backward: NULL argument");
+  GWW_REQUIRE(batch > 0 && n_targets >= 0 && (n_targets == 0 || targets), "gww_encoder_train_backward: bad argument");
+  const SavedLayout sl = saved_layout(e->cfg, batch);
+  const TrainWs w = train_ws(e->cfg, batch);
+  if (workspace_bytes < w.total || saved_bytes < sl.total)
+    return fail(GWW_ERR_WORKSPACE, "gww_encoder_train_backward: workspace / saved arena too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int d = e->cfg.d_model, F = e->cfg.ffn, T = e->cfg.t_in / 2, H = e->cfg.n_heads;
+  const int B = batch, L = e->cfg.n_layers;
+  const long M = (long)B * T;
+  char* base = (char*)workspace;
+  const char* sv = (const char*)saved;
+  float* dx = (float*)(base + w.dx);
+  void* dxb = base + w.dxb;
+  void* dbig = base + w.dbig;
+  void* dh = base + w.dh;
+  void* dctx = base + w.dctx;
+  void* dqkv = base + w.dqkv;
+  float* Dv = (float*)(base + w.Dv);
+  auto x_in = [&](int l) -> const float* { return (const float*)(sv + (l < L ? (size_t)l * sl.layer_stride + sl.x_in : (size_t)L * sl.layer_stride)); };
+  for (int i = 0; i < n_targets; ++i) {
+    const gww_dora_target& t = targets[i];
+    GWW_REQUIRE(t.layer >= 0 && t.layer < L && t.proj >= 0 && t.proj <= 3, "gww_encoder_train_backward: bad target %d", i);
+    GWW_REQUIRE(t.A && t.B && t.mag && t.nrm && t.dA && t.dB && t.dm, "gww_encoder_train_backward: NULL pointer in target %d", i);
+  }
+  // final LayerNorm backward -> dx (grad w.r.t. x_in[L])
+  GWW_TRY(launch_ln_bwd(x_in(L), e->lnw, d_last_hidden, 1, dx, 0, dxb, M, d, s));
+  for (int l = L - 1; l >= 0; --l) {
+    const LayerW& W = e->layers[l];
+    const char* lb = sv + (size_t)l * sl.layer_stride;
+    const void* h1 = lb + sl.h1;
+    const void* qkv = lb + sl.qkv;
+    const float* lse = (const float*)(lb + sl.lse);
+    const void* ctx = lb + sl.ctx;
+    const float* x_mid = (const float*)(lb + sl.x_mid);
+    const void* z = lb + sl.z;
+    // fc2 / GELU / fc1 / LN2   (x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))))
+    GWW_TRY(launch_gemm_bf16(dxb, d, W.w2T, nullptr, nullptr, nullptr, dbig, M, F, d, EPI_BIAS, 0, s, 1));
+    GWW_TRY(launch_gelu_bf16(z, dbig, dbig, ((M * F + 7) / 8) * 8, s));
+    GWW_TRY(launch_gemm_bf16(dbig, F, W.w1T, nullptr, nullptr, nullptr, dh, M, d, F, EPI_BIAS, 0, s, 1));
+    GWW_TRY(launch_ln_bwd(x_mid, W.ln2w, dh, 0, dx, 1, dxb, M, d, s));
+    // out_proj / attention / QKV / LN1   (x_mid = x_in + out_proj(attn(qkv(LN1(x_in)))))
+    for (int i = 0; i < n_targets; ++i) {
+      const gww_dora_target& t = targets[i];
+      if (t.layer == l && t.proj == 3)   // out_proj: x = ctx, y - b = x_mid - x_in is not stored in bf16: unsupported for now
+        return fail(GWW_ERR_ARG, "gww_encoder_train_backward: out_proj DoRA gradients are not implemented yet");
+    }
+    GWW_TRY(launch_gemm_bf16(dxb, d, W.woT, nullptr, nullptr, nullptr, dctx, M, d, d, EPI_BIAS, 0, s, 1));
+    GWW_TRY(launch_attention_bwd_bf16(qkv, ctx, dctx, lse, Dv, dqkv, B, T, H, s));
+    for (int i = 0; i < n_targets; ++i) {
+      const gww_dora_target& t = targets[i];
+      if (t.layer != l) continue;
+      const long off = (long)t.proj * d;   // q | k | v section
+      GWW_TRY(launch_dora_grads(h1, d, (const unsigned short*)dqkv + off, (const unsigned short*)qkv + off, 3L * d,
+                                W.bqkv + off, t.proj == 0 ? 0.125f : 1.0f, t.scaling, t.A, t.B, t.mag, t.nrm, t.dA,
+                                t.dB, t.dm, M, d, t.r, s));
+    }
+    GWW_TRY(launch_gemm_bf16(dqkv, 3L * d, W.wqkvT, nullptr, nullptr, nullptr, dh, M, d, 3 * d, EPI_BIAS, 0, s, 1));
+    GWW_TRY(launch_ln_bwd(x_in(l), W.ln1w, dh, 0, dx, 1, dxb, M, d, s));
+  }
+  if (d_x0) GWW_HIP(hipMemcpyAsync(d_x0, dx, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
   return GWW_OK;
 }

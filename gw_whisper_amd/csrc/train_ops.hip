@@ -1,0 +1,310 @@
+// Row-wise / elementwise kernels of the DoRA training step (backward of LayerNorm and GELU,
+// bf16 transposes for the dX GEMMs, and the rank-r DoRA parameter gradients).
+//
+// Reference semantics: torch autograd through HF:modeling_whisper.py:379-413 with peft 0.12.0
+// DoRA Linear (tuners/lora/dora.py: the weight norm is DETACHED), i.e. with g = m / ||W'||:
+//     y  = g * (W' x) + b,   W' = W0 + s B A
+//     dm = sum_rows dy * (W' x) / ||W'|| = sum_rows dy * (y - b) / m
+//     dB = s * (g * dy)^T (x A^T)            [out, r]
+//     dA = s * ((g * dy) B)^T x              [r, in]
+#include "common.h"
+
+namespace gww {
+
+// ---------------------------------------------------------------- LayerNorm backward
+// dx (+)= rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  one wave per row, NV float2 per lane.
+// DY_F32: dy is fp32 (grad of last_hidden_state) else bf16 (grad from a dX GEMM).
+template <int NV, bool DY_F32, bool ACCUM>
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                const void* __restrict__ dy, float* dx,
+                                                unsigned short* __restrict__ dx_bf16, long M) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  constexpr int d = NV * 128;
+  const float2* xr = reinterpret_cast<const float2*>(x + row * d);
+  const float2* g2 = reinterpret_cast<const float2*>(gamma);
+  float2 v[NV], gy[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j] = xr[lane + 64 * j];
+    s += v[j].x + v[j].y;
+  }
+  const float mean = wave_sum(s) * (1.0f / d);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j].x -= mean;
+    v[j].y -= mean;
+    q += v[j].x * v[j].x + v[j].y * v[j].y;
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / d) + 1e-5f);
+  float a = 0.f, b = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    float d0, d1;
+    if constexpr (DY_F32) {
+      const float2 t = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(dy) + row * d)[lane + 64 * j];
+      d0 = t.x; d1 = t.y;
+    } else {
+      const unsigned int t = reinterpret_cast<const unsigned int*>(reinterpret_cast<const unsigned short*>(dy) + row * d)[lane + 64 * j];
+      d0 = bf2f((unsigned short)(t & 0xffff)); d1 = bf2f((unsigned short)(t >> 16));
+    }
+    const float2 gg = g2[lane + 64 * j];
+    gy[j].x = d0 * gg.x; gy[j].y = d1 * gg.y;
+    v[j].x *= rstd; v[j].y *= rstd;                 // xhat
+    a += gy[j].x + gy[j].y;
+    b += gy[j].x * v[j].x + gy[j].y * v[j].y;
+  }
+  a = wave_sum(a) * (1.0f / d);
+  b = wave_sum(b) * (1.0f / d);
+  float2* dxr = reinterpret_cast<float2*>(dx + row * d);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    float o0 = rstd * (gy[j].x - a - v[j].x * b), o1 = rstd * (gy[j].y - a - v[j].y * b);
+    if constexpr (ACCUM) {
+      const float2 old = dxr[lane + 64 * j];
+      o0 += old.x; o1 += old.y;
+    }
+    dxr[lane + 64 * j] = make_float2(o0, o1);
+    if (dx_bf16) reinterpret_cast<unsigned int*>(dx_bf16 + row * d)[lane + 64 * j] = pack2bf(o0, o1);
+  }
+}
+
+int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int dy_f32, float* dx, int accumulate,
+                  void* dx_bf16, long M, int d, hipStream_t s) {
+  GWW_REQUIRE(d % 128 == 0 && d >= 128 && d <= 1280, "ln_bwd: d=%d must be a multiple of 128 <= 1280", d);
+  if (M == 0) return GWW_OK;
+  dim3 grid((unsigned)cdiv(M, 4)), block(256);
+  unsigned short* db = (unsigned short*)dx_bf16;
+#define GWW_LNB(NV)                                                                                               \
+  case NV:                                                                                                        \
+    if (dy_f32 && accumulate) hipLaunchKernelGGL((k_ln_bwd<NV, true, true>), grid, block, 0, s, x, gamma, dy, dx, db, M);   \
+    else if (dy_f32) hipLaunchKernelGGL((k_ln_bwd<NV, true, false>), grid, block, 0, s, x, gamma, dy, dx, db, M);          \
+    else if (accumulate) hipLaunchKernelGGL((k_ln_bwd<NV, false, true>), grid, block, 0, s, x, gamma, dy, dx, db, M);      \
+    else hipLaunchKernelGGL((k_ln_bwd<NV, false, false>), grid, block, 0, s, x, gamma, dy, dx, db, M);                     \
+    break;
+  switch (d / 128) {
+    GWW_LNB(1) GWW_LNB(2) GWW_LNB(3) GWW_LNB(4) GWW_LNB(5) GWW_LNB(6) GWW_LNB(7) GWW_LNB(8) GWW_LNB(9) GWW_LNB(10)
+  }
+#undef GWW_LNB
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+// ---------------------------------------------------------------- GELU forward / backward (bf16, 8 per lane)
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_gelu_bf16(const unsigned short* __restrict__ z,
+                                                   const unsigned short* __restrict__ df, unsigned short* out,
+                                                   long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const u32x4 zv = reinterpret_cast<const u32x4*>(z)[i];
+    u32x4 dv = {0u, 0u, 0u, 0u};
+    if constexpr (BWD) dv = reinterpret_cast<const u32x4*>(df)[i];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float z0 = bf2f((unsigned short)(zv[j] & 0xffff)), z1 = bf2f((unsigned short)(zv[j] >> 16));
+      float r0, r1;
+      if constexpr (BWD) {
+        // gelu'(z) = Phi(z) + z phi(z)
+        const float p0 = 0.5f * (1.0f + erff(z0 * 0.70710678f)) + z0 * 0.3989422804f * __expf(-0.5f * z0 * z0);
+        const float p1 = 0.5f * (1.0f + erff(z1 * 0.70710678f)) + z1 * 0.3989422804f * __expf(-0.5f * z1 * z1);
+        r0 = bf2f((unsigned short)(dv[j] & 0xffff)) * p0;
+        r1 = bf2f((unsigned short)(dv[j] >> 16)) * p1;
+      } else {
+        r0 = gelu_fast(z0);
+        r1 = gelu_fast(z1);
+      }
+      o[j] = pack2bf(r0, r1);
+    }
+    reinterpret_cast<u32x4*>(out)[i] = o;
+  }
+}
+
+int launch_gelu_bf16(const void* z, const void* df, void* out, long n, hipStream_t s) {
+  GWW_REQUIRE(n % 8 == 0, "gelu_bf16: n must be a multiple of 8");
+  if (n == 0) return GWW_OK;
+  long blocks = cdiv(n / 8, 256);
+  if (blocks > 8192) blocks = 8192;
+  if (df)
+    hipLaunchKernelGGL(k_gelu_bf16<true>, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)z,
+                       (const unsigned short*)df, (unsigned short*)out, n / 8);
+  else
+    hipLaunchKernelGGL(k_gelu_bf16<false>, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)z,
+                       (const unsigned short*)nullptr, (unsigned short*)out, n / 8);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+// ---------------------------------------------------------------- bf16 transpose [R][C] -> [C][R]
+__global__ __launch_bounds__(256) void k_transpose_bf16(const unsigned short* __restrict__ in,
+                                                        unsigned short* __restrict__ out, int R, int Cn) {
+  __shared__ unsigned short tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < Cn) ? in[(long)(r0 + r) * Cn + c0 + c] : (unsigned short)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < R && c0 + c < Cn) out[(long)(c0 + c) * R + r0 + r] = tile[r][c];
+  }
+}
+
+int launch_transpose_bf16(const void* in, void* out, int R, int Cn, hipStream_t s) {
+  dim3 grid((unsigned)cdiv(Cn, 64), (unsigned)cdiv(R, 64));
+  hipLaunchKernelGGL(k_transpose_bf16, grid, dim3(256), 0, s, (const unsigned short*)in, (unsigned short*)out, R, Cn);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+// ---------------------------------------------------------------- DoRA parameter gradients
+// One [d, d] target (q / k / v / out projection).  X [M, d] bf16 (row stride ldx), dY / Y [M, d] bf16
+// sections with row stride ldy (e.g. inside dqkv / qkv), bias_st [d] in STORED units, yscale = dy_true /
+// dy_stored (1/8 for the pre-scaled q section).  Accumulates (atomicAdd) into dA [r, d], dB [d, r], dm [d]:
+// the caller zeroes them once per step.  Each workgroup walks row tiles of 32 and keeps its partial sums
+// in registers; one pass of atomics per workgroup at the end.
+template <int D, int R>
+__global__ __launch_bounds__(256) void k_dora_grads(const unsigned short* __restrict__ X, long ldx,
+                                                    const unsigned short* __restrict__ dY,
+                                                    const unsigned short* __restrict__ Y, long ldy,
+                                                    const float* __restrict__ bias_st, float yscale, float scaling,
+                                                    const float* __restrict__ A, const float* __restrict__ Bm,
+                                                    const float* __restrict__ mag, const float* __restrict__ nrm,
+                                                    float* dA, float* dB, float* dm, long M) {
+  constexpr int RT = 32;                       // rows per tile
+  constexpr int PER = D * R / 256;             // dA / dB outputs per thread
+  static_assert(D * R % 256 == 0 && D % 8 == 0, "shape");
+  __shared__ float xs[RT][D + 1];
+  __shared__ float gs[RT][D + 1];              // g * dy_true
+  __shared__ float us[RT][R];                  // x A^T
+  __shared__ float ws[RT][R];                  // (g dy) B
+  const int tid = threadIdx.x;
+  float accA[PER], accB[PER], accM[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < PER; ++i) accA[i] = accB[i] = 0.f;
+
+  for (long r0 = (long)blockIdx.x * RT; r0 < M; r0 += (long)gridDim.x * RT) {
+    __syncthreads();
+    // stage the tile (8 bf16 per load); fold g and yscale into dy; per-column dm partials
+    for (int i = tid; i < RT * D / 8; i += 256) {
+      const int rr = i / (D / 8), c8 = (i - rr * (D / 8)) * 8;
+      const long row = r0 + rr;
+      u32x4 xv = {0u, 0u, 0u, 0u}, dv = {0u, 0u, 0u, 0u};
+      if (row < M) {
+        xv = *reinterpret_cast<const u32x4*>(X + row * ldx + c8);
+        dv = *reinterpret_cast<const u32x4*>(dY + row * ldy + c8);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xs[rr][c8 + 2 * j] = bf2f((unsigned short)(xv[j] & 0xffff));
+        xs[rr][c8 + 2 * j + 1] = bf2f((unsigned short)(xv[j] >> 16));
+        const int c = c8 + 2 * j;
+        gs[rr][c] = bf2f((unsigned short)(dv[j] & 0xffff)) * yscale * (mag[c] / nrm[c]);
+        gs[rr][c + 1] = bf2f((unsigned short)(dv[j] >> 16)) * yscale * (mag[c + 1] / nrm[c + 1]);
+      }
+    }
+    // dm: thread -> columns tid and tid + 256
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int c = tid + 256 * cc;
+      if (c < D) {
+        float sacc = 0.f;
+        for (int rr = 0; rr < RT; ++rr) {
+          const long row = r0 + rr;
+          if (row < M) {
+            const float dyv = bf2f(dY[row * ldy + c]);
+            const float yv = bf2f(Y[row * ldy + c]);
+            sacc = fmaf(dyv, yv - bias_st[c], sacc);
+          }
+        }
+        accM[cc] += sacc;
+      }
+    }
+    __syncthreads();
+    // u = x A^T, w = (g dy) B : RT * R outputs each, one (row, j) per thread (RT * R == 256)
+    {
+      const int rr = tid / R, j = tid - rr * R;
+      float su = 0.f, sw = 0.f;
+      for (int k = 0; k < D; ++k) {
+        su = fmaf(xs[rr][k], A[(long)j * D + k], su);
+        sw = fmaf(gs[rr][k], Bm[(long)k * R + j], sw);
+      }
+      us[rr][j] = su;
+      ws[rr][j] = sw;
+    }
+    __syncthreads();
+    // dB[n][j] += sum_rows gs[row][n] * us[row][j] ; dA[j][k] += sum_rows ws[row][j] * xs[row][k]
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int o = tid + 256 * i;            // flat index into [D][R] (dB) and [R][D] (dA)
+      const int nB = o / R, jB = o - nB * R;
+      const int jA = o / D, kA = o - jA * D;
+      float sb = 0.f, sa = 0.f;
+#pragma unroll 8
+      for (int rr = 0; rr < RT; ++rr) {
+        sb = fmaf(gs[rr][nB], us[rr][jB], sb);
+        sa = fmaf(ws[rr][jA], xs[rr][kA], sa);
+      }
+      accB[i] += sb;
+      accA[i] += sa;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int o = tid + 256 * i;
+    atomicAdd(dB + o, scaling * accB[i]);
+    atomicAdd(dA + o, scaling * accA[i]);
+  }
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int c = tid + 256 * cc;
+    if (c < D) atomicAdd(dm + c, accM[cc] / mag[c]);
+  }
+}
+
+int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
+                      float yscale, float scaling, const float* A, const float* Bm, const float* mag,
+                      const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s) {
+  GWW_REQUIRE(r == 8 && (d == 128 || d == 384 || d == 512), "dora_grads: only r = 8 and d in {128, 384, 512} (got d=%d r=%d)", d, r);
+  if (M == 0) return GWW_OK;
+  long blocks = cdiv(M, 32);
+  if (blocks > 1024) blocks = 1024;
+#define GWW_DG(DD)                                                                                                \
+  hipLaunchKernelGGL((k_dora_grads<DD, 8>), dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)X, ldx, \
+                     (const unsigned short*)dY, (const unsigned short*)Y, ldy, bias_st, yscale, scaling, A, Bm, mag, \
+                     nrm, dA, dB, dm, M)
+  if (d == 128) GWW_DG(128);
+  else if (d == 384) GWW_DG(384);
+  else GWW_DG(512);
+#undef GWW_DG
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+}  // namespace gww
+
+using namespace gww;
+
+extern "C" int gww_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_is_f32, float* dx,
+                                 int accumulate, void* dx_bf16, long M, int d, void* stream) {
+  GWW_REQUIRE(x && gamma && dy && dx, "gww_layernorm_bwd: NULL argument");
+  return launch_ln_bwd(x, gamma, dy, dy_is_f32, dx, accumulate, dx_bf16, M, d, (hipStream_t)stream);
+}
+
+extern "C" int gww_gelu_bf16(const void* z, const void* dgelu_or_null, void* out, long n, void* stream) {
+  GWW_REQUIRE(z && out, "gww_gelu_bf16: NULL argument");
+  return launch_gelu_bf16(z, dgelu_or_null, out, n, (hipStream_t)stream);
+}
+
+extern "C" int gww_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
+                              float yscale, float scaling, const float* A, const float* B, const float* mag,
+                              const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r,
+                              void* stream) {
+  GWW_REQUIRE(X && dY && Y && bias_st && A && B && mag && nrm && dA && dB && dm, "gww_dora_grads: NULL argument");
+  return launch_dora_grads(X, ldx, dY, Y, ldy, bias_st, yscale, scaling, A, B, mag, nrm, dA, dB, dm, M, d, r,
+                           (hipStream_t)stream);
+}

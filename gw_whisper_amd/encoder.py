@@ -231,8 +231,31 @@ class WhisperEncoder(nn.Module):
         return {lib().gww_encoder_trace_class_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
 
     def forward(self, input_features, attention_mask=None, **kwargs):
+        if torch.is_grad_enabled() and self._has_trainable_adapters():
+            # DoRA training step: HIP forward that keeps activations + HIP backward (training.py)
+            from .training import encoder_train_forward
+            self._check_input(input_features)
+            return BaseModelOutput(last_hidden_state=encoder_train_forward(self, input_features))
         hidden, _ = self.forward_raw(input_features, want_hidden=True, want_last=False)
         return BaseModelOutput(last_hidden_state=hidden)
+
+    def _has_trainable_adapters(self) -> bool:
+        for layer in self.layers:
+            for name in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                mod = getattr(layer.self_attn, name)
+                if hasattr(mod, "lora_A") and any(p.requires_grad for p in mod.lora_A.parameters()):
+                    return True
+        return False
+
+    def _check_input(self, x):
+        c = self.config
+        t_in = 2 * c.max_source_positions
+        if not x.is_cuda:
+            raise _lib.GwwError("WhisperEncoder.forward needs GPU tensors: gw_whisper_amd has no CPU fallback "
+                                f"(got input on {x.device})")
+        if x.dim() != 3 or x.shape[1] != c.num_mel_bins or x.shape[-1] != t_in:
+            raise ValueError(f"Whisper expects the mel input features to be of length {t_in}, but found "
+                             f"{x.shape[-1]}. Make sure to pad the input mel features to {t_in}.")
 
     def last_token(self, input_features) -> torch.Tensor:
         """``self(mel).last_hidden_state[:, -1, :]`` without materialising the other

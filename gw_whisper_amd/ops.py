@@ -192,3 +192,71 @@ def dora_merge(w0: torch.Tensor, a: torch.Tensor, b: torch.Tensor, m: torch.Tens
                                        float(scaling), d_out, d_in, r, out.data_ptr(), nrm.data_ptr(), _stream()),
               "gww_dora_merge_f32")
     return (out, nrm) if return_norm else out
+
+
+# ------------------------------------------------------------------ training-step kernels
+def attention_lse(qkv: torch.Tensor, n_heads: int):
+    """bf16 attention forward that also returns the row log-sum-exp [B, H, T] (fp32)."""
+    qkv = _dev(qkv, torch.bfloat16, "qkv")
+    B, T, d3 = qkv.shape
+    ctx = torch.empty((B, T, d3 // 3), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, n_heads, T), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        check(lib().gww_attention_lse_bf16(qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), B, T, n_heads, _stream()),
+              "gww_attention_lse_bf16")
+    return ctx, lse
+
+
+def attention_bwd(qkv, ctx, dctx, lse, n_heads: int) -> torch.Tensor:
+    """dqkv [B, T, 3 d] (bf16) of softmax(q k^T) v given dctx."""
+    qkv, ctx, dctx = (_dev(t, torch.bfloat16) for t in (qkv, ctx, dctx))
+    lse = _dev(lse, torch.float32, "lse")
+    B, T, d3 = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    scratch = torch.empty_like(lse)
+    with torch.cuda.device(qkv.device):
+        check(lib().gww_attention_bwd_bf16(qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(),
+                                           scratch.data_ptr(), dqkv.data_ptr(), B, T, n_heads, _stream()),
+              "gww_attention_bwd_bf16")
+    return dqkv
+
+
+def layernorm_bwd(x, gamma, dy, dx=None, want_bf16: bool = False):
+    """dx (+)= LayerNorm'(x)^T dy; dy fp32 or bf16.  Returns (dx fp32, dx bf16 | None)."""
+    x = _dev(x, torch.float32, "x")
+    M, d = x.shape
+    dy = _dev(dy)
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty_like(x)
+    dxb = torch.empty((M, d), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    with torch.cuda.device(x.device):
+        check(lib().gww_layernorm_bwd(x.data_ptr(), _dev(gamma, torch.float32).data_ptr(), dy.data_ptr(),
+                                      int(dy.dtype == torch.float32), dx.data_ptr(), int(acc),
+                                      dxb.data_ptr() if dxb is not None else None, M, d, _stream()), "gww_layernorm_bwd")
+    return dx, dxb
+
+
+def gelu_bf16(z, dgelu=None):
+    z = _dev(z, torch.bfloat16, "z")
+    out = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        check(lib().gww_gelu_bf16(z.data_ptr(), _dev(dgelu, torch.bfloat16).data_ptr() if dgelu is not None else None,
+                                  out.data_ptr(), z.numel(), _stream()), "gww_gelu_bf16")
+    return out
+
+
+def dora_grads(x, dy, y, bias_st, yscale, scaling, A, B, mag, nrm):
+    """(dA [r,d], dB [d,r], dm [d]) of one DoRA projection; x, dy, y bf16 [M, d]."""
+    x, dy, y = (_dev(t, torch.bfloat16) for t in (x, dy, y))
+    M, d = x.shape
+    r = A.shape[0]
+    dA = torch.zeros((r, d), dtype=torch.float32, device=x.device)
+    dB = torch.zeros((d, r), dtype=torch.float32, device=x.device)
+    dm = torch.zeros((d,), dtype=torch.float32, device=x.device)
+    f = lambda t: _dev(t, torch.float32).data_ptr()
+    with torch.cuda.device(x.device):
+        check(lib().gww_dora_grads(x.data_ptr(), d, dy.data_ptr(), y.data_ptr(), d, f(bias_st), float(yscale),
+                                   float(scaling), f(A), f(B), f(mag), f(nrm), dA.data_ptr(), dB.data_ptr(),
+                                   dm.data_ptr(), M, d, r, _stream()), "gww_dora_grads")
+    return dA, dB, dm

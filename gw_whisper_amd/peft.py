@@ -127,7 +127,9 @@ class DoraLinear(nn.Module):
         B = self.lora_B[self.adapter].weight.detach()
         if self.use_dora:
             m = self.lora_magnitude_vector[self.adapter].weight.detach()
-            return ops.dora_merge(W0.float(), A.float(), B.float(), m.float(), self.scaling)
+            merged, self._last_norm = ops.dora_merge(W0.float(), A.float(), B.float(), m.float(), self.scaling,
+                                                     return_norm=True)     # ||W'|| rows: the backward's detached norm
+            return merged
         # plain LoRA: same kernel with m := ||W'|| would be a no-op scale; merge = W0 + s B A
         ones = torch.ones(self.out_features, device=W0.device)
         merged, nrm = ops.dora_merge(W0.float(), A.float(), B.float(), ones, self.scaling, return_norm=True)

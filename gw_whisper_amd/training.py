@@ -1,0 +1,102 @@
+"""Autograd bridge of the DoRA training step.
+
+``encoder_train_forward(encoder, mel)`` runs the HIP training forward (activations kept in an
+arena) and returns ``last_hidden_state`` as a tensor that participates in torch autograd; its
+backward calls ``gww_encoder_train_backward`` and hands the A / B / magnitude gradients of every
+DoRA-wrapped q / k / v projection to autograd, so the reference's step
+
+    loss = criterion(model(h1, l1), labels); loss.backward(); optimizer.step()
+    (Signal_vs_Noise/src/train.py:163-168)
+
+works with the MLP head, the loss and AdamW in plain torch on the GPU and everything inside the
+encoder in libgww.  The DoRA weight norm is detached exactly like peft 0.12.0 ``dora.py``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+from .peft import DoraLinear
+
+_PROJ = {"q_proj": 0, "k_proj": 1, "v_proj": 2, "out_proj": 3}
+
+
+def dora_targets(encoder):
+    """[(layer index, proj id, DoraLinear)] of the adapted attention projections."""
+    out = []
+    for li, layer in enumerate(encoder.layers):
+        for name, pid in _PROJ.items():
+            mod = getattr(layer.self_attn, name)
+            if isinstance(mod, DoraLinear):
+                if not mod.use_dora:
+                    raise NotImplementedError("training is implemented for use_dora=True adapters")
+                out.append((li, pid, mod))
+    return out
+
+
+class _EncoderTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, encoder, mel, *params):
+        enc = encoder
+        c = enc.config
+        x = mel.to(torch.float32).contiguous()
+        B = x.shape[0]
+        dev = x.device
+        with torch.cuda.device(dev):
+            enc._sync_weights()
+            h = enc._ensure_handle()
+            ws = torch.empty((lib().gww_train_workspace_bytes(h, B),), dtype=torch.uint8, device=dev)
+            saved = torch.empty((lib().gww_train_saved_bytes(h, B),), dtype=torch.uint8, device=dev)
+            hidden = torch.empty((B, c.max_source_positions, c.d_model), dtype=torch.float32, device=dev)
+            check(lib().gww_encoder_train_forward(h, x.data_ptr(), B, ws.data_ptr(), ws.numel(), saved.data_ptr(),
+                                                  saved.numel(), hidden.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream),
+                  "gww_encoder_train_forward")
+        ctx.enc, ctx.B, ctx.ws, ctx.saved = enc, B, ws, saved
+        ctx.n_params = len(params)
+        return hidden
+
+    @staticmethod
+    def backward(ctx, d_hidden):
+        enc, B = ctx.enc, ctx.B
+        dev = d_hidden.device
+        d_hidden = d_hidden.to(torch.float32).contiguous()
+        targets = dora_targets(enc)
+        arr = (_lib.DoraTarget * max(len(targets), 1))()
+        grads, keep = [], []
+        for i, (li, pid, mod) in enumerate(targets):
+            A = mod.lora_A[mod.adapter].weight.detach().float().contiguous()
+            Bm = mod.lora_B[mod.adapter].weight.detach().float().contiguous()
+            mag = mod.lora_magnitude_vector[mod.adapter].weight.detach().float().contiguous()
+            nrm = mod._last_norm
+            dA, dB, dm = torch.zeros_like(A), torch.zeros_like(Bm), torch.zeros_like(mag)
+            keep += [A, Bm, mag]
+            grads.append((dA, dB, dm))
+            arr[i] = _lib.DoraTarget(li, pid, mod.r, float(mod.scaling), A.data_ptr(), Bm.data_ptr(), mag.data_ptr(),
+                                     nrm.data_ptr(), dA.data_ptr(), dB.data_ptr(), dm.data_ptr())
+        with torch.cuda.device(dev):
+            check(lib().gww_encoder_train_backward(enc._ensure_handle(), B, ctx.ws.data_ptr(), ctx.ws.numel(),
+                                                   ctx.saved.data_ptr(), ctx.saved.numel(), d_hidden.data_ptr(), arr,
+                                                   len(targets), None, torch.cuda.current_stream().cuda_stream),
+                  "gww_encoder_train_backward")
+        flat = []
+        for dA, dB, dm in grads:
+            flat += [dA, dB, dm]
+        assert len(flat) == ctx.n_params
+        ctx.ws = ctx.saved = None
+        return (None, None, *flat)
+
+
+def encoder_train_forward(encoder, mel: torch.Tensor) -> torch.Tensor:
+    """last_hidden_state [B, 1500, d] with autograd through the DoRA parameters."""
+    if encoder.precision != "bf16":
+        raise _lib.GwwError("the training step is implemented for precision='bf16'")
+    params = []
+    for _, _, mod in dora_targets(encoder):
+        params += [mod.lora_A[mod.adapter].weight, mod.lora_B[mod.adapter].weight,
+                   mod.lora_magnitude_vector[mod.adapter].weight]
+    return _EncoderTrain.apply(encoder, mel, *params)

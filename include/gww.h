@@ -142,6 +142,37 @@ int gww_dora_merge_f32(const float* w0, const float* a, const float* b, const fl
                        float* w_eff, float* norm_out, void* stream);
 
 /* --------------------------------------------------------------------------
+ * DoRA training step (bf16).  Replaces loss.backward() through the frozen encoder with DoRA
+ * adapters (Signal_vs_Noise/src/train.py:163-168 with the model of :263-269): the forward keeps
+ * the activations in a caller-owned arena, the backward returns the A / B / magnitude gradients
+ * of the listed projections (peft 0.12.0 dora.py semantics: the weight norm is detached) and,
+ * optionally, the gradient w.r.t. the conv-stem output.  The MLP head, the loss and the
+ * optimizer stay in torch on the GPU.
+ * -------------------------------------------------------------------------- */
+typedef struct {
+  int layer;            /* encoder layer index */
+  int proj;             /* 0 q_proj, 1 k_proj, 2 v_proj (3 out_proj: not implemented yet) */
+  int r;                /* LoRA rank (8) */
+  float scaling;        /* lora_alpha / r */
+  const float* A;       /* [r, d]   lora_A.weight */
+  const float* B;       /* [d, r]   lora_B.weight */
+  const float* mag;     /* [d]      lora_magnitude_vector */
+  const float* nrm;     /* [d]      ||W0 + s B A|| rows (norm_out of gww_dora_merge_f32) */
+  float* dA;            /* gradients, ACCUMULATED into: zero them once per step */
+  float* dB;
+  float* dm;
+} gww_dora_target;
+
+size_t gww_train_saved_bytes(const gww_encoder* enc, int batch);
+size_t gww_train_workspace_bytes(const gww_encoder* enc, int batch);
+int gww_encoder_train_forward(gww_encoder* enc, const float* mel, int batch, void* workspace,
+                              size_t workspace_bytes, void* saved, size_t saved_bytes,
+                              float* last_hidden, void* stream);
+int gww_encoder_train_backward(gww_encoder* enc, int batch, void* workspace, size_t workspace_bytes,
+                               const void* saved, size_t saved_bytes, const float* d_last_hidden,
+                               const gww_dora_target* targets, int n_targets, float* d_x0, void* stream);
+
+/* --------------------------------------------------------------------------
  * Kernel-level entry points (used by the parity tests and by the Python
  * autograd shim; same conventions).
  * -------------------------------------------------------------------------- */
@@ -182,6 +213,21 @@ int gww_gemm_f32(const float* A, const float* W, const float* bias, const float*
 /* softmax(q k^T) v per head, q pre-scaled; qkv [B,T,3*d] (q|k|v), ctx [B,T,d]; head_dim 64 */
 int gww_attention_bf16(const void* qkv, void* ctx, int B, int T, int n_heads, void* stream);
 int gww_attention_f32(const float* qkv, float* ctx, int B, int T, int n_heads, void* stream);
+/* attention backward: dqkv [B,T,3d] from qkv, ctx (forward output), dctx and the forward's lse [B,H,T]
+ * (gww_attention_lse_bf16 below); d_scratch [B,H,T] fp32 */
+int gww_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                           float* d_scratch, void* dqkv, int B, int T, int n_heads, void* stream);
+/* forward attention that also returns the row log-sum-exp lse [B,H,T] */
+int gww_attention_lse_bf16(const void* qkv, void* ctx, float* lse, int B, int T, int n_heads, void* stream);
+/* LayerNorm backward: dx (+)= dLN/dx . dy   (dy fp32 or bf16; optional bf16 copy of the result) */
+int gww_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_is_f32, float* dx,
+                      int accumulate, void* dx_bf16, long M, int d, void* stream);
+/* bf16 GELU: out = gelu(z) (dgelu == NULL) or out = dgelu * gelu'(z); n % 8 == 0 */
+int gww_gelu_bf16(const void* z, const void* dgelu_or_null, void* out, long n, void* stream);
+/* DoRA parameter gradients of one [d,d] projection (see train_ops.hip) */
+int gww_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
+                   float yscale, float scaling, const float* A, const float* B, const float* mag,
+                   const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, void* stream);
 /* fp32 -> bf16 (round to nearest even), n elements */
 int gww_cast_f32_bf16(const float* x, void* y, long n, void* stream);
 

@@ -1,0 +1,197 @@
+"""DoRA training step on the GPU: backward kernels against fp64 numpy formulas, and the whole
+encoder backward against finite differences of the fp64 oracle forward (weight norm detached,
+peft 0.12.0 dora.py).  Needs an MI355X."""
+
+import numpy as np
+import pytest
+
+from gw_whisper_amd import synth
+from oracle import dora as odora
+from oracle import encoder as oenc
+from oracle import logmel as olm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _bf(x):
+    return oenc.bf16_round(np.asarray(x, np.float32))
+
+
+def _attn_grads(qkv, dctx, H):
+    B, Tn, d3 = qkv.shape
+    d = d3 // 3
+    dq, dk, dv = np.zeros((B, Tn, d)), np.zeros((B, Tn, d)), np.zeros((B, Tn, d))
+    ctx = np.zeros((B, Tn, d))
+    lse = np.zeros((B, H, Tn))
+    for b in range(B):
+        for h in range(H):
+            sl = slice(h * 64, h * 64 + 64)
+            q, k, v = qkv[b, :, :d][:, sl], qkv[b, :, d:2 * d][:, sl], qkv[b, :, 2 * d:][:, sl]
+            s = q @ k.T
+            m = s.max(1, keepdims=True)
+            p = np.exp(s - m)
+            l = p.sum(1, keepdims=True)
+            lse[b, h] = (m + np.log(l))[:, 0]
+            p /= l
+            o = p @ v
+            ctx[b, :, sl] = o
+            do = dctx[b][:, sl]
+            dv[b, :, sl] = p.T @ do
+            dp = do @ v.T
+            D = (do * o).sum(1, keepdims=True)
+            ds = p * (dp - D)
+            dq[b, :, sl] = ds @ k
+            dk[b, :, sl] = ds.T @ q
+    return ctx, lse, np.concatenate([dq, dk, dv], axis=2)
+
+
+@pytest.mark.parametrize("B,Tn,H", [(1, 64, 1), (2, 200, 2), (1, 1500, 2)])
+def test_attention_backward(T, gww, B, Tn, H):
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(B * 100 + Tn + H)
+    qkv = _bf(rng.standard_normal((B, Tn, 3 * H * 64)) * 0.6)
+    dctx = _bf(rng.standard_normal((B, Tn, H * 64)) * 0.5)
+    ctx_ref, lse_ref, dqkv_ref = _attn_grads(qkv.astype(np.float64), dctx.astype(np.float64), H)
+    q = T.from_numpy(qkv).cuda().bfloat16()
+    ctx, lse = ops.attention_lse(q, H)
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref, atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(ctx.float().cpu().numpy(), ctx_ref, atol=6e-3, rtol=2 ** -7)
+    dqkv = ops.attention_bwd(q, ctx, T.from_numpy(dctx).cuda().bfloat16(), lse, H).float().cpu().numpy()
+    scale = np.abs(dqkv_ref).max()
+    # bf16 P / dS operands and bf16 outputs: a percent of the largest gradient entry
+    assert np.abs(dqkv - dqkv_ref).max() < 2e-2 * scale, (np.abs(dqkv - dqkv_ref).max(), scale)
+    assert np.sqrt(((dqkv - dqkv_ref) ** 2).mean()) < 3e-3 * scale
+
+
+@pytest.mark.parametrize("d", [128, 384])
+def test_layernorm_backward(T, gww, d):
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(d)
+    M = 517
+    x = (rng.standard_normal((M, d)) * 2 + 0.4).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    dy = rng.standard_normal((M, d)).astype(np.float32)
+    x64 = x.astype(np.float64)
+    mu = x64.mean(1, keepdims=True)
+    var = ((x64 - mu) ** 2).mean(1, keepdims=True)
+    rstd = 1 / np.sqrt(var + 1e-5)
+    xh = (x64 - mu) * rstd
+    gy = dy * g
+    ref = rstd * (gy - gy.mean(1, keepdims=True) - xh * (gy * xh).mean(1, keepdims=True))
+    dx, dxb = ops.layernorm_bwd(T.from_numpy(x).cuda(), T.from_numpy(g).cuda(), T.from_numpy(dy).cuda(), want_bf16=True)
+    np.testing.assert_allclose(dx.cpu().numpy(), ref, atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(dxb.float().cpu().numpy(), ref, atol=1e-5, rtol=2 ** -8)
+    # accumulate form with a bf16 dy
+    base = rng.standard_normal((M, d)).astype(np.float32)
+    dyb = _bf(dy)
+    gy = dyb.astype(np.float64) * g
+    ref2 = base + rstd * (gy - gy.mean(1, keepdims=True) - xh * (gy * xh).mean(1, keepdims=True))
+    acc = T.from_numpy(base.copy()).cuda()
+    ops.layernorm_bwd(T.from_numpy(x).cuda(), T.from_numpy(g).cuda(), T.from_numpy(dyb).cuda().bfloat16(), dx=acc)
+    np.testing.assert_allclose(acc.cpu().numpy(), ref2, atol=3e-5, rtol=1e-4)
+
+
+def test_gelu_forward_backward(T, gww):
+    from gw_whisper_amd import ops
+    from scipy.special import erf
+    rng = np.random.default_rng(1)
+    z = _bf(rng.standard_normal(8 * 4001) * 2)
+    df = _bf(rng.standard_normal(z.shape))
+    f = ops.gelu_bf16(T.from_numpy(z).cuda().bfloat16()).float().cpu().numpy()
+    np.testing.assert_allclose(f, oenc.gelu(z.astype(np.float64)), atol=1e-6, rtol=2 ** -8)
+    z64 = z.astype(np.float64)
+    gp = 0.5 * (1 + erf(z64 / np.sqrt(2))) + z64 * np.exp(-0.5 * z64 ** 2) / np.sqrt(2 * np.pi)
+    dz = ops.gelu_bf16(T.from_numpy(z).cuda().bfloat16(), T.from_numpy(df).cuda().bfloat16()).float().cpu().numpy()
+    np.testing.assert_allclose(dz, df * gp, atol=1e-6, rtol=2 ** -8)
+
+
+@pytest.mark.parametrize("d,M", [(128, 1000), (384, 777)])
+def test_dora_parameter_gradients(T, gww, d, M):
+    """dA, dB, dm of y = (m/n) (W0 + s B A) x + b with the norm detached (oracle/dora.py)."""
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(d + M)
+    W0 = (rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32)
+    A, Bm, m = synth.dora_adapter(d, d, 8, W0, seed=4)
+    s = 4.0
+    bias = (rng.standard_normal(d) * 0.1).astype(np.float32)
+    x = _bf(rng.standard_normal((M, d)))
+    dy = _bf(rng.standard_normal((M, d)) * 0.3)
+    n = odora.dora_weight_norm(W0.astype(np.float64), A.astype(np.float64), Bm.astype(np.float64), s)
+    y = _bf(odora.dora_linear_merged(x.astype(np.float64), W0.astype(np.float64), bias, A.astype(np.float64),
+                                     Bm.astype(np.float64), m.astype(np.float64), s))
+    dA_ref, dB_ref, dm_ref, _ = odora.dora_grads(x.astype(np.float64), dy.astype(np.float64), W0.astype(np.float64),
+                                                 A.astype(np.float64), Bm.astype(np.float64), m.astype(np.float64), s)
+    c = lambda a: T.from_numpy(np.asarray(a, np.float32)).cuda()
+    dA, dB, dm = ops.dora_grads(c(x).bfloat16(), c(dy).bfloat16(), c(y).bfloat16(), c(bias), 1.0, s, c(A), c(Bm), c(m), c(n))
+    np.testing.assert_allclose(dA.cpu().numpy(), dA_ref, atol=2e-3 * np.abs(dA_ref).max(), rtol=1e-3)
+    np.testing.assert_allclose(dB.cpu().numpy(), dB_ref, atol=2e-3 * np.abs(dB_ref).max(), rtol=1e-3)
+    # dm uses the bf16-rounded y in place of W'x: a looser bound
+    np.testing.assert_allclose(dm.cpu().numpy(), dm_ref, atol=2e-2 * np.abs(dm_ref).max(), rtol=2e-2)
+
+
+def test_training_step_matches_finite_differences(T, gww):
+    """loss.backward() through the HIP encoder (DoRA on q, k, v of a 2-layer d=128 encoder) against
+    central finite differences of the fp64 oracle forward with the weight norm frozen (detached)."""
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    from gw_whisper_amd.peft import LoraConfig, get_peft_model
+    cfg = oenc.EncCfg(128, 2, 2, 512)
+    sd = synth.encoder_state_dict(128, 2, 2, 512, seed=3)
+    mel = olm.log_mel(synth.strain_segments(2, seed=33))
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig(128, 2, 2, 512), precision="bf16")
+    targets = [f"layers.{i}.self_attn.{p}" for i in range(2) for p in ("q_proj", "k_proj", "v_proj")]
+    peft = get_peft_model(enc, LoraConfig(use_dora=True, r=8, lora_alpha=32, target_modules=targets)).cuda()
+    theta = {}
+    with T.no_grad():
+        for j, name in enumerate(targets):
+            lin = peft.base_model.model.get_submodule(name)
+            A, Bm, m = synth.dora_adapter(128, 128, 8, sd[name + ".weight"], seed=70 + j)
+            lin.lora_A["default"].weight.copy_(T.from_numpy(A))
+            lin.lora_B["default"].weight.copy_(T.from_numpy(Bm))
+            lin.lora_magnitude_vector["default"].weight.copy_(T.from_numpy(m))
+            theta[name] = [A.astype(np.float64), Bm.astype(np.float64), m.astype(np.float64)]
+    rng = np.random.default_rng(0)
+    wloss = rng.standard_normal((2, 128))
+
+    # ---- GPU: loss = sum(w * last_token); backward through libgww
+    hidden = peft(T.from_numpy(mel).cuda()).last_hidden_state
+    assert hidden.requires_grad
+    loss = (hidden[:, -1, :] * T.from_numpy(wloss).cuda().float()).sum()
+    loss.backward()
+    grads = {}
+    for name in targets:
+        lin = peft.base_model.model.get_submodule(name)
+        grads[name] = [lin.lora_A["default"].weight.grad.double().cpu().numpy(),
+                       lin.lora_B["default"].weight.grad.double().cpu().numpy(),
+                       lin.lora_magnitude_vector["default"].weight.grad.double().cpu().numpy()]
+        assert all(np.isfinite(g).all() and np.abs(g).max() > 0 for g in grads[name])
+    assert all(p.grad is None for n, p in peft.named_parameters() if "lora_" not in n)   # base stays frozen
+
+    # ---- oracle: same loss as a function of theta with the norm detached
+    n0 = {k: odora.dora_weight_norm(sd[k + ".weight"].astype(np.float64), v[0], v[1], 4.0) for k, v in theta.items()}
+
+    def loss_of(th):
+        sd2 = {k: v.astype(np.float64) for k, v in sd.items()}
+        for k, (A, Bm, m) in th.items():
+            Wp = sd[k + ".weight"].astype(np.float64) + 4.0 * (Bm @ A)
+            sd2[k + ".weight"] = (m / n0[k])[:, None] * Wp
+        out = oenc.encoder_forward(sd2, mel, cfg, dtype=np.float64)
+        return float((out[:, -1, :] * wloss).sum())
+
+    ref_loss = loss_of(theta)
+    assert abs(float(loss) - ref_loss) < 3e-2 * max(1.0, abs(ref_loss))
+    eps = 1e-3
+    for trial in range(3):
+        v = {k: [rng.standard_normal(a.shape) for a in th] for k, th in theta.items()}
+        plus = {k: [a + eps * dv for a, dv in zip(theta[k], v[k])] for k in theta}
+        minus = {k: [a - eps * dv for a, dv in zip(theta[k], v[k])] for k in theta}
+        fd = (loss_of(plus) - loss_of(minus)) / (2 * eps)
+        an = sum(float((g * dv).sum()) for k in theta for g, dv in zip(grads[k], v[k]))
+        print(f"directional derivative {trial}: analytic(HIP, bf16) {an:.5f}  finite-difference(fp64 oracle) {fd:.5f}")
+        assert abs(an - fd) < 0.06 * abs(fd) + 2e-3, (an, fd)
