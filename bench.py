@@ -113,6 +113,60 @@ def kernel_breakdown(enc_name, B, dev):
     return rows
 
 
+def dora_step(enc_name, per_gpu_batch, dev, world, steps=3, warmup=1):
+    """DoRA fine-tuning step as in Signal_vs_Noise/src/train.py:163-168,263-277: whisper encoder with
+    DoRA (r=8, alpha=32) on q/k/v, two-detector MLP head, BCEWithLogits, AdamW over the 'lora' + head
+    parameters; forward + backward in libgww, head / loss / optimizer in torch; gradients of the
+    trainable parameters all-reduced over RCCL in ONE flat bucket when world > 1."""
+    import fnmatch
+    from gw_whisper_amd import dist as gdist, ops, synth
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    from gw_whisper_amd.models import two_channel_ligo_binary_classifier
+    from gw_whisper_amd.peft import LoraConfig, get_peft_model
+    torch.manual_seed(0)
+    sd = synth.named_encoder_state_dict(enc_name, seed=0)
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig.named(enc_name), precision="bf16")
+    pats = ["layers.*.self_attn.q_proj", "layers.*.self_attn.k_proj", "layers.*.self_attn.v_proj",
+            "layers.*.self_attn.o_proj"]
+    targets = [n for n, _ in enc.named_modules() if any(fnmatch.fnmatch(n, p) for p in pats)]
+    peft = get_peft_model(enc, LoraConfig(use_dora=True, r=8, lora_alpha=32, target_modules=targets))
+    for name, p in peft.named_parameters():
+        p.requires_grad = "lora" in name
+    model = two_channel_ligo_binary_classifier(peft).to(dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4)
+    bucket = gdist.FlatGradBucket(params)
+    crit = torch.nn.BCEWithLogitsLoss()
+    rank = int(os.environ.get("RANK", "0"))
+    h1 = ops.logmel(torch.from_numpy(synth.strain_segments(per_gpu_batch, seed=7 + rank)).to(dev))
+    l1 = ops.logmel(torch.from_numpy(synth.strain_segments(per_gpu_batch, seed=77 + rank)).to(dev))
+    labels = (torch.arange(per_gpu_batch, device=dev) % 2).float()[:, None]
+    times = {"fwd": 0.0, "bwd": 0.0, "allreduce": 0.0, "opt": 0.0}
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    total = 0.0
+    for it in range(warmup + steps):
+        e = [ev() for _ in range(5)]
+        bucket.zero()
+        e[0].record()
+        loss = crit(model(h1, l1), labels)
+        e[1].record()
+        loss.backward()
+        e[2].record()
+        bucket.all_reduce_mean(world)
+        e[3].record()
+        opt.step()
+        e[4].record()
+        torch.cuda.synchronize()
+        if it >= warmup:
+            for k, i in (("fwd", 0), ("bwd", 1), ("allreduce", 2), ("opt", 3)):
+                times[k] += e[i].elapsed_time(e[i + 1]) / steps
+            total += e[0].elapsed_time(e[4]) / steps
+    assert torch.isfinite(loss).all()
+    return {"ms": total, "split_ms": times, "per_gpu_batch": per_gpu_batch, "detectors": 2,
+            "trainable_params": int(bucket.numel), "adapter": "DoRA r=8 alpha=32 on q,k,v (12 modules on tiny)",
+            "loss": float(loss.detach())}
+
+
 def cpu_baseline(enc_name, n_seg=24):
     """The numpy oracle (a CPU port of the HF arithmetic, not the reference itself) on a
     bounded sample: n_seg segments of the same workload, all host cores via BLAS."""
@@ -147,6 +201,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-kernel event trace")
     ap.add_argument("--split", type=int, default=1, help="1 (default): two half batches on two HIP streams; 0: one stream")
+    ap.add_argument("--no-train", action="store_true", help="skip the DoRA step timing")
+    ap.add_argument("--train-batch", type=int, default=32, help="per-GPU batch of the DoRA step (reference default 32)")
     ap.add_argument("--isolated", action="store_true", help="also time each kernel class in isolation")
     args = ap.parse_args()
 
@@ -212,6 +268,13 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
+    train = None
+    if not args.no_train and args.precision == "bf16":
+        del out
+        enc._ws = None
+        torch.cuda.empty_cache()
+        train = dora_step(args.encoder, args.train_batch, dev, world)
+
     if rank == 0:
         fl = flops_per_segment(d, L, H, ffn)
         fwd_tflops = B * fl["total"] / (ms_per_step * 1e-3) / 1e12
@@ -230,7 +293,8 @@ def main():
                          "segments_per_s": B / fe_ms * 1e3,
                          "algorithmic_gbs": B * (64000 + 960000) / fe_ms / 1e6,
                          "frac_of_hbm_peak": B * (64000 + 960000) / fe_ms / 1e6 / HBM_PEAK_GBS},
-            "dora_step_ms": None,
+            "dora_step_ms": train["ms"] if train else None,
+            "dora_step": train,
         }
         if traced:
             M = B * T_TOK

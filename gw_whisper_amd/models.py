@@ -38,9 +38,11 @@ class two_channel_ligo_binary_classifier(nn.Module):
             nn.Linear(256, num_classes))
 
     def forward(self, mel_tensor_0, mel_tensor_1):
-        output_h1 = _pooled(self.encoder, mel_tensor_0)
-        output_l1 = _pooled(self.encoder, mel_tensor_1)
-        return self.classifier(torch.cat((output_h1, output_l1), dim=1))
+        # both detectors share the encoder weights: one pass over the stacked batch (same arithmetic
+        # as the reference's two sequential calls, segments are independent)
+        n = mel_tensor_0.shape[0]
+        both = _pooled(self.encoder, torch.cat((mel_tensor_0, mel_tensor_1), dim=0))
+        return self.classifier(torch.cat((both[:n], both[n:]), dim=1))
 
 
 class one_channel_ligo_binary_classifier(nn.Module):
