@@ -25,6 +25,7 @@ int launch_transpose_bf16(const void* in, void* out, int R, int Cn, hipStream_t 
 int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int dy_f32, float* dx, int accumulate,
                   void* dx_bf16, long M, int d, hipStream_t s);
 int launch_gelu_bf16(const void* z, const void* df, void* out, long n, hipStream_t s);
+int launch_sub_f32_bf16(const float* a, const float* b, void* out, long n, hipStream_t s);
 int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
                       float yscale, float scaling, const float* A, const float* Bm, const float* mag,
                       const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s);
@@ -414,14 +415,16 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   GWW_HIP(hipMemsetAsync((char*)melT + (size_t)B * (Tin + 2) * C * es, 0, kConv1Kpad * es, s));
   GWW_HIP(hipMemsetAsync(c1, 0, (size_t)d * es, s));   // zero row 0 of batch 0 (token -1)
   // A-stationary kernels (A panel in registers, fused residual-add + LayerNorm prologue) for K = d <= 512
-  const bool astat = bf && (d == 384 || d == 512) && F % 128 == 0;
-  if (bf && d % 128 == 0)
+  // GWW_GENERIC_PATH (debug aid): bit 0 = generic layer GEMMs, bit 1 = generic conv1, bit 2 = generic conv2
+  static const int generic_mask = getenv("GWW_GENERIC_PATH") ? atoi(getenv("GWW_GENERIC_PATH")) : 0;
+  const bool astat = bf && (d == 384 || d == 512) && F % 128 == 0 && !(generic_mask & 1);
+  if (bf && d % 128 == 0 && !(generic_mask & 2))
     TR(TR_CONV1, launch_gemm_astat(melT, C, nullptr, nullptr, nullptr, nullptr, e->c1w, e->c1b, c1,
                                    (long)B * (Tin + 2), d, kConv1Kpad, EPI_CONV1, Tin + 2, s));
   else
     TR(TR_CONV1, gemm(melT, C, e->c1w, e->c1w32, e->c1b, nullptr, nullptr, c1, (long)B * (Tin + 2), d, kConv1Kpad,
                       EPI_CONV1, Tin + 2));
-  if (bf && (d == 384 || d == 512))
+  if (bf && (d == 384 || d == 512) && !(generic_mask & 4))
     TR(TR_CONV2, launch_gemm_fulln(c1, 2L * d, e->c2w, e->c2b, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2, T + 1, s));
   else
     TR(TR_CONV2, gemm(c1, 2L * d, e->c2w, e->c2w32, e->c2b, nullptr, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2,
@@ -669,16 +672,24 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
     GWW_TRY(launch_gemm_bf16(dbig, F, W.w1T, nullptr, nullptr, nullptr, dh, M, d, F, EPI_BIAS, 0, s, 1));
     GWW_TRY(launch_ln_bwd(x_mid, W.ln2w, dh, 0, dx, 1, dxb, M, d, s));
     // out_proj / attention / QKV / LN1   (x_mid = x_in + out_proj(attn(qkv(LN1(x_in)))))
-    for (int i = 0; i < n_targets; ++i) {
-      const gww_dora_target& t = targets[i];
-      if (t.layer == l && t.proj == 3)   // out_proj: x = ctx, y - b = x_mid - x_in is not stored in bf16: unsupported for now
-        return fail(GWW_ERR_ARG, "gww_encoder_train_backward: out_proj DoRA gradients are not implemented yet");
+    {   // out_proj DoRA targets: x = ctx, dy = d(x_mid) (= dxb), y = x_mid - x_in (rebuilt into dh, free here)
+      bool have_y = false;
+      for (int i = 0; i < n_targets; ++i) {
+        const gww_dora_target& t = targets[i];
+        if (t.layer != l || t.proj != 3) continue;
+        if (!have_y) {
+          GWW_TRY(launch_sub_f32_bf16(x_mid, x_in(l), dh, M * d, s));
+          have_y = true;
+        }
+        GWW_TRY(launch_dora_grads(ctx, d, dxb, dh, d, W.bo, 1.0f, t.scaling, t.A, t.B, t.mag, t.nrm, t.dA, t.dB, t.dm,
+                                  M, d, t.r, s));
+      }
     }
     GWW_TRY(launch_gemm_bf16(dxb, d, W.woT, nullptr, nullptr, nullptr, dctx, M, d, d, EPI_BIAS, 0, s, 1));
     GWW_TRY(launch_attention_bwd_bf16(qkv, ctx, dctx, lse, Dv, dqkv, B, T, H, s));
     for (int i = 0; i < n_targets; ++i) {
       const gww_dora_target& t = targets[i];
-      if (t.layer != l) continue;
+      if (t.layer != l || t.proj == 3) continue;
       const long off = (long)t.proj * d;   // q | k | v section
       GWW_TRY(launch_dora_grads(h1, d, (const unsigned short*)dqkv + off, (const unsigned short*)qkv + off, 3L * d,
                                 W.bqkv + off, t.proj == 0 ? 0.125f : 1.0f, t.scaling, t.A, t.B, t.mag, t.nrm, t.dA,

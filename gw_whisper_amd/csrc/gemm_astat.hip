@@ -265,7 +265,8 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* Aany, 
         // D >= KT: every k-tile of the NEXT n-tile is already in flight when an epilogue issues its
         // stores, so those stores may stay outstanding for a whole n-tile (any smaller count is
         // merely conservative: vmcnt retires in order)
-        if (nti > 0) as_wait_vmcnt<AS_GLDS * (AS_D - 1) + AS_STORES>();
+        // (k-tiles S >= D of this n-tile were issued AFTER those stores: no allowance for them -- K = 512)
+        if (nti > 0 && S < AS_D) as_wait_vmcnt<AS_GLDS * (AS_D - 1) + AS_STORES>();
         else as_wait_vmcnt<AS_GLDS * (AS_D - 1)>();
       } else {
         as_wait_vmcnt<0>();   // tail: fewer groups in flight than the constant assumes
@@ -357,8 +358,9 @@ int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, 
   if (M == 0) return GWW_OK;
   const long panels = cdiv(M, AS_BM);
   const int tiles_n = N / AS_BN;
-  int n_split = as_pick_split(panels, tiles_n);
-  while (tiles_n / n_split > 12) n_split *= 2;   // lds_bias holds 1536 columns
+  // with a delta every workgroup of a row panel rewrites the same x_new values: keep the split minimal
+  int n_split = delta ? 1 : as_pick_split(panels, tiles_n);
+  while (cdiv(tiles_n, n_split) > 12) n_split *= 2;   // lds_bias / lds_u hold 1536 columns
   int valid_rows = 0;
   if (epi == EPI_CONV1) {
     GWW_REQUIRE(rows_per_batch > 2, "gemm_astat: conv1 epilogue needs rows_per_batch");
@@ -371,7 +373,7 @@ int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, 
   GWW_REQUIRE(ln || (!delta && !x_out), "gemm_astat: delta / x_out need the LayerNorm prologue");
   GWW_REQUIRE(!ln || lda == K, "gemm_astat: fused LayerNorm needs lda == K");
   GWW_REQUIRE((delta == nullptr) == (x_out == nullptr), "gemm_astat: delta and x_out go together");
-  if (delta) n_split = 1;   // x_new is written back by exactly one workgroup per row panel
+  GWW_REQUIRE(!x_out || (const void*)x_out != A, "gemm_astat: x_out must not alias the input stream");
   dim3 grid((unsigned)(panels * n_split)), block(AS_THREADS);
 #define GWW_AS_LAUNCH(E, AM, KT, HD)                                                                        \
   hipLaunchKernelGGL((k_gemm_astat<E, AM, KT, HD>), grid, block, 0, s, A, lda, (const unsigned short*)delta,  \

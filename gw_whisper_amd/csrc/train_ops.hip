@@ -161,6 +161,31 @@ int launch_transpose_bf16(const void* in, void* out, int R, int Cn, hipStream_t 
   return GWW_OK;
 }
 
+// ---------------------------------------------------------------- bf16(a - b) of two fp32 tensors
+// out_proj's output is never stored on its own (it is fused into the residual add): its DoRA magnitude
+// gradient needs y = x_mid - x_in, rebuilt here.
+__global__ __launch_bounds__(256) void k_sub_f32_bf16(const float* __restrict__ a, const float* __restrict__ b,
+                                                      unsigned short* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 av = reinterpret_cast<const f32x4*>(a)[i];
+    const f32x4 bv = reinterpret_cast<const f32x4*>(b)[i];
+    u32x2 o;
+    o[0] = pack2bf(av[0] - bv[0], av[1] - bv[1]);
+    o[1] = pack2bf(av[2] - bv[2], av[3] - bv[3]);
+    reinterpret_cast<u32x2*>(out)[i] = o;
+  }
+}
+
+int launch_sub_f32_bf16(const float* a, const float* b, void* out, long n, hipStream_t s) {
+  GWW_REQUIRE(n % 4 == 0, "sub_f32_bf16: n must be a multiple of 4");
+  if (n == 0) return GWW_OK;
+  long blocks = cdiv(n / 4, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_sub_f32_bf16, dim3((unsigned)blocks), dim3(256), 0, s, a, b, (unsigned short*)out, n / 4);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
 // ---------------------------------------------------------------- DoRA parameter gradients
 // One [d, d] target (q / k / v / out projection).  X [M, d] bf16 (row stride ldx), dY / Y [M, d] bf16
 // sections with row stride ldy (e.g. inside dqkv / qkv), bias_st [d] in STORED units, yscale = dy_true /
@@ -175,15 +200,18 @@ __global__ __launch_bounds__(256) void k_dora_grads(const unsigned short* __rest
                                                     const float* __restrict__ A, const float* __restrict__ Bm,
                                                     const float* __restrict__ mag, const float* __restrict__ nrm,
                                                     float* dA, float* dB, float* dm, long M) {
-  constexpr int RT = 32;                       // rows per tile
+  constexpr int RT = D <= 512 ? 32 : (D <= 1024 ? 16 : 8);   // rows per tile (two fp32 tiles must fit in LDS)
   constexpr int PER = D * R / 256;             // dA / dB outputs per thread
-  static_assert(D * R % 256 == 0 && D % 8 == 0, "shape");
+  constexpr int CC = (D + 255) / 256;          // dm columns per thread
+  static_assert(D * R % 256 == 0 && D % 8 == 0 && RT * R <= 256, "shape");
   __shared__ float xs[RT][D + 1];
   __shared__ float gs[RT][D + 1];              // g * dy_true
   __shared__ float us[RT][R];                  // x A^T
   __shared__ float ws[RT][R];                  // (g dy) B
   const int tid = threadIdx.x;
-  float accA[PER], accB[PER], accM[2] = {0.f, 0.f};
+  float accA[PER], accB[PER], accM[CC];
+#pragma unroll
+  for (int i = 0; i < CC; ++i) accM[i] = 0.f;
 #pragma unroll
   for (int i = 0; i < PER; ++i) accA[i] = accB[i] = 0.f;
 
@@ -207,9 +235,9 @@ __global__ __launch_bounds__(256) void k_dora_grads(const unsigned short* __rest
         gs[rr][c + 1] = bf2f((unsigned short)(dv[j] >> 16)) * yscale * (mag[c + 1] / nrm[c + 1]);
       }
     }
-    // dm: thread -> columns tid and tid + 256
+    // dm: thread -> columns tid, tid + 256, ...
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
+    for (int cc = 0; cc < CC; ++cc) {
       const int c = tid + 256 * cc;
       if (c < D) {
         float sacc = 0.f;
@@ -225,8 +253,8 @@ __global__ __launch_bounds__(256) void k_dora_grads(const unsigned short* __rest
       }
     }
     __syncthreads();
-    // u = x A^T, w = (g dy) B : RT * R outputs each, one (row, j) per thread (RT * R == 256)
-    {
+    // u = x A^T, w = (g dy) B : RT * R outputs each, one (row, j) per thread (RT * R <= 256)
+    if (tid < RT * R) {
       const int rr = tid / R, j = tid - rr * R;
       float su = 0.f, sw = 0.f;
       for (int k = 0; k < D; ++k) {
@@ -260,7 +288,7 @@ __global__ __launch_bounds__(256) void k_dora_grads(const unsigned short* __rest
     atomicAdd(dA + o, scaling * accA[i]);
   }
 #pragma unroll
-  for (int cc = 0; cc < 2; ++cc) {
+  for (int cc = 0; cc < CC; ++cc) {
     const int c = tid + 256 * cc;
     if (c < D) atomicAdd(dm + c, accM[cc] / mag[c]);
   }
@@ -269,9 +297,10 @@ __global__ __launch_bounds__(256) void k_dora_grads(const unsigned short* __rest
 int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
                       float yscale, float scaling, const float* A, const float* Bm, const float* mag,
                       const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s) {
-  GWW_REQUIRE(r == 8 && (d == 128 || d == 384 || d == 512), "dora_grads: only r = 8 and d in {128, 384, 512} (got d=%d r=%d)", d, r);
+  GWW_REQUIRE(r == 8 && (d == 128 || d == 384 || d == 512 || d == 768 || d == 1024 || d == 1280),
+              "dora_grads: only r = 8 and d in {128, 384, 512, 768, 1024, 1280} (got d=%d r=%d)", d, r);
   if (M == 0) return GWW_OK;
-  long blocks = cdiv(M, 32);
+  long blocks = cdiv(M, d <= 512 ? 32 : (d <= 1024 ? 16 : 8));
   if (blocks > 1024) blocks = 1024;
 #define GWW_DG(DD)                                                                                                \
   hipLaunchKernelGGL((k_dora_grads<DD, 8>), dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)X, ldx, \
@@ -279,7 +308,10 @@ int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, lo
                      nrm, dA, dB, dm, M)
   if (d == 128) GWW_DG(128);
   else if (d == 384) GWW_DG(384);
-  else GWW_DG(512);
+  else if (d == 512) GWW_DG(512);
+  else if (d == 768) GWW_DG(768);
+  else if (d == 1024) GWW_DG(1024);
+  else GWW_DG(1280);
 #undef GWW_DG
   GWW_LAUNCH_CHECK();
   return GWW_OK;

@@ -124,12 +124,13 @@ class WhisperEncoder(nn.Module):
 
     # ---- library plumbing
     def __del__(self):
-        h, self._handle = getattr(self, "_handle", None), None
-        if h is not None:
-            try:
+        try:   # may run during interpreter shutdown, when torch's module globals are already gone
+            h = self.__dict__.get("_handle")
+            self.__dict__["_handle"] = None
+            if h is not None:
                 lib().gww_encoder_destroy(h)
-            except Exception:
-                pass
+        except Exception:
+            pass
 
     def _ensure_handle(self):
         if self._handle is None:

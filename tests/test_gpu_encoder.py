@@ -207,3 +207,29 @@ def test_dual_stream_split_is_bit_identical(T, gww):
         b_h, b_l = enc.forward_raw(mel, want_hidden=True, want_last=True)
         T.cuda.synchronize()
     assert T.equal(a_h, b_h) and T.equal(a_l, b_l)
+
+
+@pytest.mark.parametrize("name", ["base", "small"])
+def test_named_sizes_match_oracle(T, gww, name):
+    """whisper-base (BASELINE config 4) and whisper-small (configs 3 and 5) geometry, one segment:
+    fp32 path vs the fp32 oracle, bf16 path within bf16 tolerance of it, last_token == hidden[:, -1]."""
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    d, L, H, F = synth.ENCODER_SIZES[name]
+    sd = synth.encoder_state_dict(d, L, H, F, seed=5)
+    mel = olm.log_mel(synth.strain_segments(1, seed=9))
+    ref = oenc.encoder_forward(sd, mel, oenc.EncCfg(d, L, H, F), dtype=np.float32)
+    x = T.from_numpy(mel).cuda()
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig.named(name), precision="fp32").cuda()
+    with T.no_grad():
+        out32 = enc(x).last_hidden_state.cpu().numpy()
+        last32 = enc.last_token(x).cpu().numpy()
+    e32 = np.abs(out32 - ref).max()
+    print(f"[{name}] fp32 max |hidden - oracle| = {e32:.3e}")
+    assert e32 < 1e-3
+    np.testing.assert_allclose(last32, out32[:, -1], atol=1e-5)
+    enc.precision = "bf16"
+    with T.no_grad():
+        out16 = enc(x).last_hidden_state.cpu().numpy()
+    e16 = np.abs(out16 - ref).max()
+    print(f"[{name}] bf16 max |hidden - oracle| = {e16:.3e} (|hidden| max {np.abs(ref).max():.2f})")
+    assert e16 < 0.15 and np.abs(out16 - ref).mean() < 6e-3

@@ -136,7 +136,7 @@ def test_gemm_bf16(T, gww, M, N, K, epi):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 128, 384), (1500, 1152, 384), (3000, 384, 384), (777, 1536, 384),
-                                   (512, 256, 256), (300, 512, 512), (5000, 1536, 384)])
+                                   (512, 256, 256), (300, 512, 512), (5000, 1536, 384), (6000, 1024, 512)])
 @pytest.mark.parametrize("epi", [0, 1])
 def test_gemm_astat_bf16(T, gww, M, N, K, epi):
     """A panel held in registers, W through the LDS-DMA ring (gemm_astat.hip)."""
@@ -155,7 +155,8 @@ def test_gemm_astat_bf16(T, gww, M, N, K, epi):
     np.testing.assert_allclose(got, ref, atol=1e-5 * np.sqrt(K), rtol=2 ** -8)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 1152, 384), (1500, 1536, 384), (700, 512, 512)])
+@pytest.mark.parametrize("M,N,K", [(256, 1152, 384), (1500, 1536, 384), (700, 512, 512), (3000, 2048, 512),
+                                   (9000, 1536, 512)])
 @pytest.mark.parametrize("epi", [0, 1])
 @pytest.mark.parametrize("with_delta", [False, True])
 def test_gemm_astat_fused_layernorm(T, gww, M, N, K, epi, with_delta):
