@@ -108,6 +108,10 @@ def kernel_breakdown(enc_name, B, dev):
         add("gemm_fc1_gelu", lambda: ops.gemm(h, w1, b1, 1), B * 2 * T_TOK * d * ffn, M * (d + ffn) * 2)
     if astat:
         add("gemm_fc2", lambda: ops.gemm_fulln(f1, w2, bo, 0), B * 2 * T_TOK * d * ffn, M * (ffn * 2 + d * 2))
+    if d == 384:
+        wt = ops.mlp_pack(w1_f, w2)
+        add("mlp_fused(ln+fc1+gelu+fc2)", lambda: ops.mlp_fused(x32, h, wt, u1, c1, bo),
+            B * 4 * T_TOK * d * ffn, M * d * 12)
     else:
         add("gemm_fc2_resid", lambda: ops.gemm(f1, w2, bo, 2, resid=x32), B * 2 * T_TOK * d * ffn, M * (ffn * 2 + d * 8))
     return rows
@@ -310,6 +314,7 @@ def main():
                 "ln+fc1_gelu": (B * 2 * T_TOK * d * ffn, M * (d * 4 + ffn * es)),
                 "fc2": (B * 2 * T_TOK * d * ffn, M * (ffn + d) * es),
                 "final_layernorm": (0, M * d * 8),
+                "mlp_fused(ln+fc1+gelu+fc2)": (B * 4 * T_TOK * d * ffn, M * d * (4 + 2 + 4 + 2)),
             }
             rows = []
             for name, (ms, cnt) in traced.items():

@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgww.so")
+LIB_PATH = os.environ.get("GWW_LIB") or os.path.join(_HERE, "libgww.so")   # GWW_LIB: tuning builds only
 
 PREC_BF16 = 0
 PREC_F32 = 1
@@ -88,6 +88,8 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gww_gemm_fulln_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p]),
+    "gww_mlp_fused_bf16": (C.c_int, [C.c_void_p] * 8 + [C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "gww_mlp_pack_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gww_gemm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gww_attention_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -26,6 +26,9 @@ int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int dy_f32
                   void* dx_bf16, long M, int d, hipStream_t s);
 int launch_gelu_bf16(const void* z, const void* df, void* out, long n, hipStream_t s);
 int launch_sub_f32_bf16(const float* a, const float* b, void* out, long n, hipStream_t s);
+int launch_mlp_pack(const void* w1_folded, const void* w2, void* out, int d, int F, hipStream_t s);
+int launch_mlp_fused(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
+                     const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s);
 int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
                       float yscale, float scaling, const float* A, const float* Bm, const float* mag,
                       const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s);
@@ -46,6 +49,7 @@ struct LayerW {
   float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
   // LayerNorm-folded panels for the A-stationary GEMMs (gain folded into W, see gemm_astat.hip)
   unsigned short *wqkv_ln, *w1_ln;
+  unsigned short* wmlp;   // fused-MLP weight stream (d = 384): mlp_fused.hip
   float *uqkv, *cbqkv, *u1, *cb1;
   // transposed bf16 panels [K][N] for the dX GEMMs of the training backward
   unsigned short *wqkvT, *woT, *w1T, *w2T;
@@ -58,7 +62,7 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 }  // namespace
 
 // kernel classes of one forward, for the optional per-kernel event trace (bench.py roofline)
-enum : int { TR_MEL = 0, TR_CONV1, TR_CONV2, TR_QKV, TR_ATTN, TR_OUT, TR_FC1, TR_FC2, TR_LN, TR_COUNT };
+enum : int { TR_MEL = 0, TR_CONV1, TR_CONV2, TR_QKV, TR_ATTN, TR_OUT, TR_FC1, TR_FC2, TR_LN, TR_MLP, TR_COUNT };
 
 struct TraceSpan { int cls; hipEvent_t a, b; };
 
@@ -101,7 +105,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
   const size_t o_c1b = take(d * 4), o_c2b = take(d * 4), o_pos = take((size_t)T * d * 4);
   const size_t o_lnw = take(d * 4), o_lnb = take(d * 4);
   struct LO { size_t wqkv, wo, w1, w2, wqkv32, wo32, w132, w232, bqkv, bo, b1, b2, ln1w, ln1b, ln2w, ln2b,
-                     wqkv_ln, w1_ln, uqkv, cbqkv, u1, cb1, wqkvT, woT, w1T, w2T; };
+                     wqkv_ln, w1_ln, uqkv, cbqkv, u1, cb1, wqkvT, woT, w1T, w2T, wmlp; };
   std::vector<LO> lo(L);
   for (int i = 0; i < L; ++i) {
     lo[i].wqkv = take((size_t)3 * d * d * 2);
@@ -122,6 +126,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
     lo[i].ln2b = take(d * 4);
     lo[i].wqkv_ln = take((size_t)3 * d * d * 2);
     lo[i].w1_ln = take((size_t)F * d * 2);
+    lo[i].wmlp = take((size_t)2 * F * d * 2);
     lo[i].uqkv = take(3 * d * 4);
     lo[i].cbqkv = take(3 * d * 4);
     lo[i].u1 = take(F * 4);
@@ -168,6 +173,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
     w.ln2b = (float*)(p + lo[i].ln2b);
     w.wqkv_ln = (unsigned short*)(p + lo[i].wqkv_ln);
     w.w1_ln = (unsigned short*)(p + lo[i].w1_ln);
+    w.wmlp = (unsigned short*)(p + lo[i].wmlp);
     w.uqkv = (float*)(p + lo[i].uqkv);
     w.cbqkv = (float*)(p + lo[i].cbqkv);
     w.u1 = (float*)(p + lo[i].u1);
@@ -208,7 +214,7 @@ extern "C" int gww_encoder_trace_read(gww_encoder* e, float* ms, int* counts) {
 extern "C" int gww_encoder_trace_classes(void) { return TR_COUNT; }
 extern "C" const char* gww_encoder_trace_class_name(int i) {
   static const char* names[TR_COUNT] = {"mel_to_tokens", "conv1_gelu", "conv2_gelu_pos", "ln+qkv_proj", "attention",
-                                        "out_proj", "ln+fc1_gelu", "fc2", "final_layernorm"};
+                                        "out_proj", "ln+fc1_gelu", "fc2", "final_layernorm", "mlp_fused(ln+fc1+gelu+fc2)"};
   return (i >= 0 && i < TR_COUNT) ? names[i] : "?";
 }
 
@@ -283,6 +289,7 @@ extern "C" int gww_encoder_set_weights(gww_encoder* e, const gww_enc_globals* g,
     GWW_TRY(launch_ln_fold(L.v_w, L.ln1_w, L.ln1_b, L.v_b, 1.f, d, d, w.wqkv_ln + 2 * dd, w.uqkv + 2 * d,
                            w.cbqkv + 2 * d, s));
     GWW_TRY(launch_ln_fold(L.fc1_w, L.ln2_w, L.ln2_b, L.fc1_b, 1.f, F, d, w.w1_ln, w.u1, w.cb1, s));
+    if (d == 384 && F % 128 == 0 && F <= 1536) GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, w.wmlp, d, F, s));
     // transposed panels for the backward dX GEMMs:  [N][K] -> [K][N]
     GWW_TRY(launch_transpose_bf16(w.wqkv, w.wqkvT, 3 * d, d, s));
     GWW_TRY(launch_transpose_bf16(w.wo, w.woT, d, d, s));
@@ -415,9 +422,10 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   GWW_HIP(hipMemsetAsync((char*)melT + (size_t)B * (Tin + 2) * C * es, 0, kConv1Kpad * es, s));
   GWW_HIP(hipMemsetAsync(c1, 0, (size_t)d * es, s));   // zero row 0 of batch 0 (token -1)
   // A-stationary kernels (A panel in registers, fused residual-add + LayerNorm prologue) for K = d <= 512
-  // GWW_GENERIC_PATH (debug aid): bit 0 = generic layer GEMMs, bit 1 = generic conv1, bit 2 = generic conv2
+  // GWW_GENERIC_PATH (debug aid): bit 0 = generic layer GEMMs, bit 1 = generic conv1, bit 2 = generic conv2, bit 3 = unfused MLP
   static const int generic_mask = getenv("GWW_GENERIC_PATH") ? atoi(getenv("GWW_GENERIC_PATH")) : 0;
   const bool astat = bf && (d == 384 || d == 512) && F % 128 == 0 && !(generic_mask & 1);
+  const bool mlp_fused = astat && d == 384 && F <= 1536 && !(generic_mask & 8);   // bit 3 = separate fc1 / fc2 kernels
   if (bf && d % 128 == 0 && !(generic_mask & 2))
     TR(TR_CONV1, launch_gemm_astat(melT, C, nullptr, nullptr, nullptr, nullptr, e->c1w, e->c1b, c1,
                                    (long)B * (Tin + 2), d, kConv1Kpad, EPI_CONV1, Tin + 2, s));
@@ -445,9 +453,15 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
       if (i == 0 && skew_event) GWW_HIP(hipEventRecord(skew_event, s));   // the other half batch starts here
       TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s));
       TR(TR_OUT, launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, L.wo, L.bo, d1, M, d, d, EPI_BIAS, 0, s));
-      TR(TR_FC1, launch_gemm_astat(xc, d, d1, xn, L.u1, L.cb1, L.w1_ln, nullptr, f1, M, F, d, EPI_GELU, 0, s));
-      { float* t = xc; xc = xn; xn = t; }
-      TR(TR_FC2, launch_gemm_fulln(f1, F, L.w2, L.b2, nullptr, d2, M, d, F, EPI_BIAS, 0, s));
+      if (mlp_fused) {
+        // LN2 + fc1 + GELU + fc2 in one kernel: the [M, ffn] activation never leaves the CU
+        TR(TR_MLP, launch_mlp_fused(xc, d1, xn, L.u1, L.cb1, L.wmlp, L.b2, d2, M, d, F, s));
+        { float* t = xc; xc = xn; xn = t; }
+      } else {
+        TR(TR_FC1, launch_gemm_astat(xc, d, d1, xn, L.u1, L.cb1, L.w1_ln, nullptr, f1, M, F, d, EPI_GELU, 0, s));
+        { float* t = xc; xc = xn; xn = t; }
+        TR(TR_FC2, launch_gemm_fulln(f1, F, L.w2, L.b2, nullptr, d2, M, d, F, EPI_BIAS, 0, s));
+      }
       pending = d2;
     }
   } else {

@@ -1,0 +1,493 @@
+// Fused MLP block of one encoder layer at d_model = 384 (whisper-tiny), bf16 MFMA:
+//
+//     x_new = x + delta                      (deferred residual of out_proj, written back, fp32)
+//     out   = fc2( gelu( fc1( LayerNorm(x_new) ) ) ) + b2          (bf16 delta for the next layer)
+//
+// HF:modeling_whisper.py:401-407 (final_layer_norm -> fc1 -> activation_fn -> fc2; the residual add of
+// :407 is deferred to the consumer exactly like the A-stationary GEMMs do, gemm_astat.hip).
+//
+// Why: as two kernels (LN+fc1+GELU, then fc2) the [M, ffn] activation makes a 2.4 GB HBM round trip per
+// layer at B = 256 and the GELU epilogue (VALU) cannot overlap any MFMA.  Here the ffn activation never
+// leaves the CU and most of the GELU work runs beside the fc2 MFMAs:
+//
+//   * one workgroup = 128 rows = 4 waves x 32 rows, ONE wave per SIMD with the whole 512-register file:
+//     A operand (LayerNorm'd x, whole K = 384) 96 VGPRs, fc1 chunk accumulator [32 x 128] 64, output
+//     accumulator [32 x 384] 192.
+//   * the ffn dimension is walked in chunks of 128:  S = a W1'[chunk]^T (96 MFMAs), LayerNorm algebra +
+//     bias + GELU on S in registers, and the bf16 result IS the B operand of the second product
+//     O += P W2[:, chunk]^T (96 MFMAs) -- the accumulator-as-operand trick of attention.hip; W2 is packed
+//     with bits 2 and 3 of k swapped inside every 16-group so that its fragments are plain 16-byte reads.
+//   * W1' / W2 stream through ONE ring of [128 rows][64 k] bf16 tiles (16 KB, XOR-swizzled, LDS-DMA with
+//     source-side swizzle, counted vmcnt, one raw s_barrier per tile): 12 tiles per chunk, 16 MFMAs per
+//     wave per tile.  Waits run one tile ahead so the first fragments of the next tile are read before
+//     its barrier.
+//   * prologue / epilogue as in gemm_astat.hip: whole-line loads of x / delta, wave-private LDS transposes,
+//     single-pass algebraic LayerNorm, whole-line stores of the bf16 output.
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace gww {
+
+namespace {
+constexpr int MF_D = 384;                  // d_model this kernel is built for
+constexpr int MF_KT = MF_D / 64;           // 6 k-tiles of fc1
+constexpr int MF_OT = MF_D / 32;           // 12 output sub-tiles of fc2
+constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
+#ifndef GWW_MF_EXP
+#define GWW_MF_EXP 0   // diagnostic builds only: 1 = no DMA in the loop, 2 = no GELU, 4 = no fragment reads in the loop
+#endif
+#ifndef GWW_MF_AHEAD
+#define GWW_MF_AHEAD 6
+#endif
+constexpr int MF_AHEAD = GWW_MF_AHEAD, MF_NST = MF_AHEAD + 1;   // tiles in flight ahead of the one being computed, ring stages
+constexpr int MF_TILE = 128 * 64 * 2;      // 16 KB
+constexpr int MF_GL = 16 / MF_WAVES;       // LDS-DMA pieces per thread per tile
+constexpr int MF_TPC = 12;                 // tiles per ffn chunk: 6 of W1', 6 of W2
+constexpr int MF_FMAX = 1536;              // largest ffn (cb / u staged in LDS)
+constexpr int MF_SLICE_STRIDE = 144, MF_SLICE_BYTES = 32 * MF_SLICE_STRIDE;
+constexpr int MF_OFF_CB = MF_NST * MF_TILE;
+constexpr int MF_OFF_U = MF_OFF_CB + MF_FMAX * 4;
+constexpr int MF_OFF_B2 = MF_OFF_U + MF_FMAX * 4;
+constexpr int MF_OFF_SLICE = MF_OFF_B2 + MF_D * 4;
+constexpr int MF_LDS = MF_OFF_SLICE + MF_WAVES * MF_SLICE_BYTES;
+static_assert(MF_LDS <= 160 * 1024, "LDS budget");
+
+template <int N>
+__device__ __forceinline__ void mf_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// x * sigmoid(p(x)),  p an odd quintic fitted to the erf GELU: |err| <= 2.6e-5 on the whole real line
+// (x^2 clamped at 64 keeps p monotone); 7 plain VALU ops + v_exp_f32 + v_rcp_f32.
+__device__ __forceinline__ float gelu_sig(float x) {
+  const float s = fminf(x * x, 64.0f);
+  float q = fmaf(s, 0.0010148164f, -0.1067791331f);     // -log2(e) * (a5 s + a3)
+  q = fmaf(s, q, -2.3011178f);                          // -log2(e) * a1
+  const float e = __builtin_amdgcn_exp2f(x * q);        // exp(-p(x))
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// ---- optional in-kernel phase stamps (diagnostic build only: -DGWW_STAMP), cycles per phase
+#ifdef GWW_STAMP
+__device__ unsigned long long g_stamp_mlp[24];
+#define MSTAMP_DECL unsigned long long _t0 = __builtin_amdgcn_s_memtime(); unsigned long long _acc[20] = {0};
+#define MSTAMP(i)                                                  \
+  do {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    const unsigned long long _t1 = __builtin_amdgcn_s_memtime();   \
+    _acc[i] += _t1 - _t0;                                          \
+    _t0 = _t1;                                                     \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+#define MSTAMP_FLUSH                                                                 \
+  if (lane == 0) {                                                                   \
+    for (int _q = 0; _q < 20; ++_q) atomicAdd(&g_stamp_mlp[_q], _acc[_q]);           \
+    atomicAdd(&g_stamp_mlp[23], 1ull);                                                \
+  }
+#else
+#define MSTAMP_DECL
+#define MSTAMP(i)
+#define MSTAMP_FLUSH
+#endif
+}  // namespace
+
+__global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, const unsigned short* delta, float* x_out,
+                                                            const float* __restrict__ ln_u,
+                                                            const float* __restrict__ ln_cb,
+                                                            const unsigned short* __restrict__ Wt,
+                                                            const float* __restrict__ b2,
+                                                            unsigned short* __restrict__ C, long M, int F,
+                                                            int stagger_ticks) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[MF_LDS];
+  float* lds_cb = reinterpret_cast<float*>(lds + MF_OFF_CB);
+  float* lds_u = reinterpret_cast<float*>(lds + MF_OFF_U);
+  float* lds_b2 = reinterpret_cast<float*>(lds + MF_OFF_B2);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const long m_base = (long)blockIdx.x * MF_BM + wave * 32;
+  unsigned char* slice = lds + MF_OFF_SLICE + wave * MF_SLICE_BYTES;
+  const int crow = lane >> 3, cchunk = lane & 7;
+  const int nch = F / 128;
+
+  // ---- ring: the weights arrive pre-tiled (gww_mlp_pack_bf16): tile (c, idx) is 16 contiguous KiB that
+  // already hold the swizzled LDS image, in the order the loop consumes them, so the whole weight stream
+  // is one linear walk; piece j of this wave = 1 KiB = one wave-instruction
+  // SGPR base + per-lane 32-bit byte offset (no VALU address arithmetic per piece: a VALU write into a
+  // register an in-flight MFMA still reads stalls the wave); M0 = wave-uniform LDS destination.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lane_off = (unsigned)lane * 16u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr)lds;
+  auto issue_piece = [&](int c, int idx, int stage, int j) {
+    const unsigned dst = lds_base + (unsigned)(stage * MF_TILE + (MF_GL * wave_u + j) * 1024);
+    const unsigned short* src = Wt + ((long)(c * MF_TPC + idx) * (MF_TILE / 2) + (MF_GL * wave_u + j) * 512);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_off), "s"(src), "s"(dst)
+                 : "memory");
+  };
+  auto issue = [&](int c, int idx, int stage) {
+#pragma unroll
+    for (int j = 0; j < MF_GL; ++j) issue_piece(c, idx, stage, j);
+  };
+
+  MSTAMP_DECL
+  for (int i = tid; i < F; i += MF_THREADS) {
+    lds_cb[i] = ln_cb[i];
+    lds_u[i] = ln_u[i];
+  }
+  for (int i = tid; i < MF_D; i += MF_THREADS) lds_b2[i] = b2[i];
+  // De-phase the first round of workgroups (later ones inherit the offsets as CUs free up): panels take
+  // the same time everywhere, so without this every CU is in its HBM phase (prologue / epilogue) at the
+  // same moment and idles HBM during the MFMA phase.
+  if (stagger_ticks > 0 && blockIdx.x < 256) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 7) * stagger_ticks;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
+
+  // ---- prologue: x_new = x + delta (written back), a = bf16(x_new - c), exact fp32 row statistics
+  bf16x8 af[MF_KT * 4];
+  float row_rstd, row_mean;
+  long grow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long g = m_base + 8 * i + crow;
+    grow[i] = g < M ? g : M - 1;
+  }
+  {
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, cshift[4];
+    // All loads of three k-tiles (48 per lane, 144 registers) are issued before the first use -- two exposed
+    // round trips per panel instead of six; the accumulators are not live yet, the register file is free.
+    // hipcc sinks plain loads back next to their uses, so the loads are asm and counted by hand: loads and
+    // stores retire in order, pair k (x, delta) is complete once at most 46 - 2 k younger loads + the k
+    // x_new stores issued since are outstanding.
+    const float* xrow[4];
+    const unsigned short* drow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xrow[i] = X + grow[i] * MF_D + 4 * cchunk;
+      drow[i] = delta + grow[i] * MF_D + 4 * cchunk;
+    }
+#pragma unroll
+    for (int S3 = 0; S3 < MF_KT; S3 += 3) {
+      f32x4 xv[3][2][4];
+      u32x2 dv[3][2][4];
+#pragma unroll
+      for (int S = 0; S < 3; ++S)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
+                         : "=v"(xv[S][h2][i]) : "v"(xrow[i]), "n"((64 * (S3 + S) + 32 * h2) * 4) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, off offset:%2"
+                         : "=v"(dv[S][h2][i]) : "v"(drow[i]), "n"((64 * (S3 + S) + 32 * h2) * 2) : "memory");
+          }
+#pragma unroll
+      for (int Sl = 0; Sl < 3; ++Sl) {
+        const int S = S3 + Sl;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xv[Sl][h2][i]), "+v"(dv[Sl][h2][i]) : "n"(46 - (8 * Sl + 4 * h2 + i)));
+            f32x4 v = xv[Sl][h2][i];
+            v[0] += bf2f((unsigned short)(dv[Sl][h2][i][0] & 0xffff));
+            v[1] += bf2f((unsigned short)(dv[Sl][h2][i][0] >> 16));
+            v[2] += bf2f((unsigned short)(dv[Sl][h2][i][1] & 0xffff));
+            v[3] += bf2f((unsigned short)(dv[Sl][h2][i][1] >> 16));
+            *reinterpret_cast<f32x4*>(x_out + grow[i] * MF_D + 64 * S + 32 * h2 + 4 * cchunk) = v;
+            asm volatile("" ::: "memory");   // keep the store count of the next wait exact
+            if (S == 0 && h2 == 0) {
+              float t = (v[0] + v[1]) + (v[2] + v[3]);
+              t += __shfl_xor(t, 1, 64);
+              t += __shfl_xor(t, 2, 64);
+              t += __shfl_xor(t, 4, 64);
+              cshift[i] = t * (1.0f / 32.0f);
+            }
+            v[0] -= cshift[i]; v[1] -= cshift[i]; v[2] -= cshift[i]; v[3] -= cshift[i];
+            s1[i] += (v[0] + v[1]) + (v[2] + v[3]);
+            s2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8) = o;
+          }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          u32x4 u = *reinterpret_cast<const u32x4*>(slice + r * MF_SLICE_STRIDE + (4 * hh + j) * 16);
+          asm volatile("" : "+v"(u)::"memory");
+          af[4 * S + j] = __builtin_bit_cast(bf16x8, u);
+        }
+      }
+    }
+    float* stat = reinterpret_cast<float*>(slice);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = s1[i], b = s2[i];
+      a += __shfl_xor(a, 1, 64); b += __shfl_xor(b, 1, 64);
+      a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64);
+      a += __shfl_xor(a, 4, 64); b += __shfl_xor(b, 4, 64);
+      const float mean = a * (1.0f / MF_D);
+      const float var = fmaxf(b * (1.0f / MF_D) - mean * mean, 0.f);
+      if (cchunk == 0) {
+        stat[8 * i + crow] = rsqrtf(var + 1e-5f);
+        stat[32 + 8 * i + crow] = mean;
+      }
+    }
+    row_rstd = stat[r];
+    row_mean = stat[32 + r];
+    asm volatile("" : "+v"(row_rstd), "+v"(row_mean)::"memory");
+  }
+  mf_wait_vmcnt<0>();   // every ordinary load / store is retired before the ring starts counting
+  MSTAMP(0);
+#pragma unroll
+  for (int p = 0; p < MF_AHEAD; ++p) issue(0, p, p);
+
+  // per-lane LDS offsets of the W fragments inside a tile: row 32 t + r, 16-byte chunk index
+  //   fc1 tile, k-step j : chunk 4 hh + j      fc2 tile, k-step s : chunk 2 s + hh
+  int off1[4], off2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    off1[j] = r * 128 + (((4 * hh + j) ^ ((r >> 1) & 7)) << 4);
+    off2[j] = r * 128 + (((2 * j + hh) ^ ((r >> 1) & 7)) << 4);
+  }
+
+  f32x16 sacc[4], oacc[MF_OT];
+#pragma unroll
+  for (int t = 0; t < MF_OT; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) oacc[t][j] = 0.f;
+  u32x4 pf[4][2];   // bf16 operand fragments of fc2: pf[t][s] = gelu(S[t]) registers 8 s .. 8 s + 7
+
+  // Activation piece p = 4 t + cc of chunk c: LayerNorm algebra + bias + GELU on registers 4 cc .. 4 cc + 3 of
+  // S[t], one value per call so that the VALU work can be spread over the gaps between MFMAs.
+  float a_u[2][4], a_b[2][4], a_v[2][4];
+  auto act_begin = [&](int slot, int c, int p) {
+    if (GWW_MF_EXP & 2) return;
+    const int nl = 128 * c + 32 * (p >> 2) + 8 * (p & 3) + 4 * hh;
+    const float4 uv = *reinterpret_cast<const float4*>(lds_u + nl);
+    const float4 bv = *reinterpret_cast<const float4*>(lds_cb + nl);
+    a_u[slot][0] = uv.x; a_u[slot][1] = uv.y; a_u[slot][2] = uv.z; a_u[slot][3] = uv.w;
+    a_b[slot][0] = bv.x; a_b[slot][1] = bv.y; a_b[slot][2] = bv.z; a_b[slot][3] = bv.w;
+  };
+  auto act_val = [&](int slot, int p, int e) {
+    if (GWW_MF_EXP & 2) return;
+    a_v[slot][e] = gelu_sig(fmaf(row_rstd, fmaf(-row_mean, a_u[slot][e], sacc[p >> 2][4 * (p & 3) + e]), a_b[slot][e]));
+  };
+  auto act_end = [&](int slot, int p) {
+    if (GWW_MF_EXP & 2) return;
+    const int t = p >> 2, cc = p & 3;
+    pf[t][cc >> 1][2 * (cc & 1)] = pack2bf(a_v[slot][0], a_v[slot][1]);
+    pf[t][cc >> 1][2 * (cc & 1) + 1] = pack2bf(a_v[slot][2], a_v[slot][3]);
+    asm volatile("" : "+v"(pf[t][cc >> 1][2 * (cc & 1)]), "+v"(pf[t][cc >> 1][2 * (cc & 1) + 1]));
+  };
+  // pieces riding in a step: p0 in gap 0, p1 (if any) in gap 2; the four values of a piece are independent
+  // chains (ILP 4 hides the v_exp / v_rcp latency); act_end pins the result here (hipcc would sink the whole
+  // computation to its first use, after the last fc2 k-half)
+  auto act_piece = [&](int slot, int c, int p) {
+    act_begin(slot, c, p);
+    act_val(slot, p, 0); act_val(slot, p, 1); act_val(slot, p, 2); act_val(slot, p, 3);
+    act_end(slot, p);
+  };
+  auto act_gap = [&](int c, int p0, int p1, int u) {
+    if (u == 0 && p0 >= 0) act_piece(0, c, p0);
+    if (u == 2 && p1 >= 0) act_piece(1, c, p1);
+  };
+
+  // tile 0 landed (younger tiles may still be in flight)
+  mf_wait_vmcnt<MF_GL*(MF_AHEAD - 1)>();
+  __builtin_amdgcn_s_barrier();
+
+  // W fragments are read one step (4 MFMAs) ahead of their use, across tile boundaries too: the waits
+  // below run one tile ahead, so tile it + 1 is complete and visible while tile it is being computed.
+  // Inside a step every MFMA is followed by its share of the other work (one fragment read, one DMA piece,
+  // a slice of GELU): those issue while the MFMA runs instead of after the group of four.
+  bf16x8 wf[2][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) wf[0][t] = *reinterpret_cast<const bf16x8*>(lds + t * 4096 + off1[0]);
+
+  int stage = 0;   // ring stage of the tile being computed
+  for (int c = 0; c < nch; ++c) {
+#pragma unroll
+    for (int idx = 0; idx < MF_TPC; ++idx) {
+      // tile it = 12 c + idx.  Wait for tile it + 1; the barrier also says every wave is done with tile
+      // it - 1, whose stage receives tile it + MF_AHEAD.
+      if (c == nch - 1 && idx >= MF_TPC - (MF_AHEAD - 1)) mf_wait_vmcnt<0>();
+      else mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
+      __builtin_amdgcn_s_barrier();
+      MSTAMP(1);
+      const int dma_idx = idx + MF_AHEAD < MF_TPC ? idx + MF_AHEAD : idx + MF_AHEAD - MF_TPC;
+      const int dma_c = idx + MF_AHEAD < MF_TPC ? c : c + 1;
+      const int dma_stage = stage + MF_AHEAD >= MF_NST ? stage + MF_AHEAD - MF_NST : stage + MF_AHEAD;
+      const int stage_next = stage + 1 == MF_NST ? 0 : stage + 1;
+      MSTAMP(2);
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        const int q = 4 * idx + sub;
+        bf16x8(&cur)[4] = wf[q & 1];
+        bf16x8(&nxt)[4] = wf[(q + 1) & 1];
+        const int nidx = sub == 3 ? (idx + 1 == MF_TPC ? 0 : idx + 1) : idx;
+        const int nsub = (sub + 1) & 3;
+        const unsigned char* Wn = lds + (sub == 3 ? stage_next : stage) * MF_TILE + (nidx < MF_KT ? off1[nsub] : off2[nsub]);
+        // activation pieces riding in this step
+        int p0 = -1, p1 = -1;
+        if (idx == MF_KT - 1 && sub == 3) { p0 = 0; p1 = 1; }          // S[0] is final after this step's first MFMA
+        if (idx >= MF_KT) {
+          const int q2 = 4 * (idx - MF_KT) + sub;                       // 0 .. 23 over the six fc2 tiles
+          if (q2 < 3) { p0 = 2 + 2 * q2; p1 = 3 + 2 * q2; }
+          else if (q2 < 11) p0 = 5 + q2;
+        }
+        const int i2 = idx - MF_KT, kh = i2 / 3, ng = i2 - 3 * kh;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (idx < MF_KT) {
+            // ---- fc1: S[u] (+)= W1' tile (rows 32 u ..) . a[k-tile idx, k-step sub]
+            if (idx == 0 && sub == 0) {
+              f32x16 z;
+#pragma unroll
+              for (int j = 0; j < 16; ++j) z[j] = 0.f;
+              sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[u], af[4 * idx + sub], z, 0, 0, 0);
+            } else {
+              sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[u], af[4 * idx + sub], sacc[u], 0, 0, 0);
+            }
+          } else {
+            // ---- fc2: O[4 ng + u] += W2 tile (rows 32 u ..) . P[k-step]
+            oacc[4 * ng + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                cur[u], __builtin_bit_cast(bf16x8, pf[2 * kh + (sub >> 1)][sub & 1]), oacc[4 * ng + u], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(GWW_MF_EXP & 4)) nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + u * 4096);
+          if (u == 0 && !(GWW_MF_EXP & 1) && dma_c < nch) issue_piece(dma_c, dma_idx, dma_stage, sub);
+          if (idx == MF_KT - 1 && sub == 3) {
+            // pieces 0 and 1 (both of S[0]) wait for the first MFMA of this step: gaps 2 and 3
+            if (u == 2) act_piece(0, c, 0);
+            if (u == 3) act_piece(1, c, 1);
+          } else {
+            act_gap(c, p0, p1, u);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      stage = stage_next;
+      MSTAMP(8 + idx);
+    }
+  }
+
+  // ---- epilogue: + b2 -> bf16 -> wave-private LDS transpose -> whole-line stores
+#pragma unroll
+  for (int np = 0; np < MF_OT / 2; ++np) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = 2 * np + tt;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int nl = 32 * t + 8 * cc + 4 * hh;
+        const float4 bv = *reinterpret_cast<const float4*>(lds_b2 + nl);
+        u32x2 o = {pack2bf(oacc[t][4 * cc] + bv.x, oacc[t][4 * cc + 1] + bv.y),
+                   pack2bf(oacc[t][4 * cc + 2] + bv.z, oacc[t][4 * cc + 3] + bv.w)};
+        *reinterpret_cast<u32x2*>(slice + r * MF_SLICE_STRIDE + (32 * tt + 8 * cc + 4 * hh) * 2) = o;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4 u = *reinterpret_cast<const u32x4*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + cchunk * 16);
+      const long orow = m_base + 8 * i + crow;
+      *reinterpret_cast<u32x4*>(C + orow * MF_D + np * 64 + 8 * cchunk) = u;
+    }
+  }
+  MSTAMP(3);
+  MSTAMP_FLUSH
+}
+
+// Pre-tile the two weight panels of the block into the stream k_mlp_fused consumes:
+//   out[c][idx] = one 16-KiB LDS image [128 rows][64 k], 16-byte chunks XOR-swizzled by (row >> 1) & 7
+//   idx < 6 : W1'[128 c + row][64 idx + k]                                   (gain-folded fc1, [F, 384])
+//   idx >= 6: i2 = idx - 6, kh = i2 / 3, ng = i2 % 3: W2[128 ng + row][128 c + 64 kh + swap23(k)]
+// swap23 exchanges bits 2 and 3 of k: the operand order of the accumulator-as-operand product (header).
+__global__ __launch_bounds__(256) void k_mlp_pack(const unsigned short* __restrict__ w1,
+                                                  const unsigned short* __restrict__ w2,
+                                                  unsigned short* __restrict__ out, int F, long n_chunks16) {
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < n_chunks16; g += (long)gridDim.x * 256) {
+    const int tile = (int)(g >> 10), within = (int)(g & 1023);
+    const int row = within >> 3, chunk = (within & 7) ^ ((row >> 1) & 7);
+    const int c = tile / MF_TPC, idx = tile - c * MF_TPC;
+    u32x4 v;
+    if (idx < MF_KT) {
+      v = *reinterpret_cast<const u32x4*>(w1 + (long)(128 * c + row) * MF_D + 64 * idx + 8 * chunk);
+    } else {
+      const int i2 = idx - MF_KT, kh = i2 / 3, ng = i2 - 3 * kh;
+      const unsigned short* src = w2 + (long)(128 * ng + row) * F + 128 * c + 64 * kh;
+      unsigned short e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int p = 8 * chunk + j;
+        e[j] = src[(p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1)];
+      }
+      v = u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+    }
+    reinterpret_cast<u32x4*>(out)[g] = v;
+  }
+}
+
+// w1_folded bf16 [F, 384], w2 bf16 [384, F] -> out bf16, 2 * 384 * F elements
+int launch_mlp_pack(const void* w1_folded, const void* w2, void* out, int d, int F, hipStream_t s) {
+  GWW_REQUIRE(d == MF_D && F % 128 == 0 && F > 0, "mlp_pack: d must be 384 and ffn a multiple of 128");
+  const long n16 = 2L * MF_D * F / 8;
+  hipLaunchKernelGGL(k_mlp_pack, dim3((unsigned)cdiv(n16, 256)), dim3(256), 0, s, (const unsigned short*)w1_folded,
+                     (const unsigned short*)w2, (unsigned short*)out, F, n16);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+// x fp32 [M, 384], delta bf16 [M, 384], x_out fp32 [M, 384] (!= x); Wt = launch_mlp_pack of the gain-folded fc1
+// panel and the fc2 panel, ln_u / ln_cb from gww_ln_fold_weights; C bf16 [>= roundup(M, 128), 384] (whole
+// 128-row panels are stored).
+int launch_mlp_fused(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
+                     const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s) {
+  GWW_REQUIRE(x && delta && x_out && ln_u && ln_cb && Wt && b2 && C, "mlp_fused: NULL operand");
+  GWW_REQUIRE(d == MF_D, "mlp_fused: built for d_model = 384 (got %d)", d);
+  GWW_REQUIRE(F % 128 == 0 && F > 0 && F <= MF_FMAX, "mlp_fused: ffn = %d must be a multiple of 128, <= 1536", F);
+  GWW_REQUIRE((const void*)x_out != (const void*)x, "mlp_fused: x_out must not alias x");
+  GWW_REQUIRE(((((uintptr_t)x) | ((uintptr_t)delta) | ((uintptr_t)x_out) | ((uintptr_t)Wt) | ((uintptr_t)C)) & 15) == 0,
+              "mlp_fused: operands must be 16-byte aligned");
+  if (M == 0) return GWW_OK;
+  const long panels = cdiv(M, MF_BM);
+  // stagger only when there is more than one round of workgroups to keep de-phased; 100 MHz ticks
+  static const int stagger_env = getenv("GWW_MLP_STAGGER") ? atoi(getenv("GWW_MLP_STAGGER")) : -1;
+  const int stagger = panels >= 512 ? (stagger_env >= 0 ? stagger_env : 500 * F / 1536) : 0;
+  hipLaunchKernelGGL(k_mlp_fused, dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta,
+                     x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+}  // namespace gww
+
+using namespace gww;
+
+#ifdef GWW_STAMP
+extern "C" int gww_debug_stamps_mlp(unsigned long long* out8, int reset) {
+  GWW_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(gww::g_stamp_mlp), sizeof(unsigned long long) * 24));
+  if (reset) {
+    unsigned long long z[24] = {0};
+    GWW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gww::g_stamp_mlp), z, sizeof(z)));
+  }
+  return GWW_OK;
+}
+#endif
+
+extern "C" int gww_mlp_pack_bf16(const void* w1_folded, const void* w2, void* out, int d, int F, void* stream) {
+  GWW_REQUIRE(w1_folded && w2 && out, "gww_mlp_pack_bf16: NULL argument");
+  return launch_mlp_pack(w1_folded, w2, out, d, F, (hipStream_t)stream);
+}
+
+extern "C" int gww_mlp_fused_bf16(const float* x, const void* delta, float* x_out, const float* ln_u,
+                                  const float* ln_cb, const void* Wt, const float* b2, void* C, long M, int d,
+                                  int F, void* stream) {
+  return launch_mlp_fused(x, delta, x_out, ln_u, ln_cb, Wt, b2, C, M, d, F, (hipStream_t)stream);
+}

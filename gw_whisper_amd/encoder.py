@@ -23,6 +23,7 @@ Calling the module with CPU tensors raises -- there is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 from dataclasses import dataclass
 
 import torch
@@ -124,10 +125,12 @@ class WhisperEncoder(nn.Module):
 
     # ---- library plumbing
     def __del__(self):
-        try:   # may run during interpreter shutdown, when torch's module globals are already gone
+        try:
             h = self.__dict__.get("_handle")
             self.__dict__["_handle"] = None
-            if h is not None:
+            # at interpreter shutdown the HIP runtime may already be torn down: the process exit frees the
+            # device memory, calling into the library then can block
+            if h is not None and not sys.is_finalizing():
                 lib().gww_encoder_destroy(h)
         except Exception:
             pass

@@ -163,6 +163,37 @@ def gemm_fulln(a: torch.Tensor, w: torch.Tensor, bias=None, epilogue: int = 0) -
     return c[:M]
 
 
+def mlp_pack(w1_folded: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """Weight stream of mlp_fused: folded fc1 panel [F, 384] + fc2 panel [384, F] -> bf16 [2 * 384 * F]."""
+    w1 = _dev(w1_folded, torch.bfloat16, "W1")
+    w2 = _dev(w2, torch.bfloat16, "W2")
+    F, d = w1.shape
+    out = torch.empty((2 * d * F,), dtype=torch.bfloat16, device=w1.device)
+    with torch.cuda.device(w1.device):
+        check(lib().gww_mlp_pack_bf16(w1.data_ptr(), w2.data_ptr(), out.data_ptr(), d, F, _stream()),
+              "gww_mlp_pack_bf16")
+    return out
+
+
+def mlp_fused(x, delta, wt, ln_u, ln_cb, b2):
+    """(C bf16 [M, 384], x_new fp32 [M, 384]) = fused LayerNorm -> fc1 -> GELU -> fc2 of x + delta."""
+    x = _dev(x, torch.float32, "x")
+    delta = _dev(delta, torch.bfloat16, "delta")
+    wt = _dev(wt, torch.bfloat16, "Wt")
+    M, d = x.shape
+    F = ln_u.numel()
+    Mp = (M + 127) // 128 * 128
+    c = torch.empty((Mp, d), dtype=torch.bfloat16, device=x.device)
+    x_out = torch.empty_like(x)
+    f = lambda t: _dev(t, torch.float32)
+    u, cb, b2 = f(ln_u), f(ln_cb), f(b2)
+    with torch.cuda.device(x.device):
+        check(lib().gww_mlp_fused_bf16(x.data_ptr(), delta.data_ptr(), x_out.data_ptr(), u.data_ptr(), cb.data_ptr(),
+                                       wt.data_ptr(), b2.data_ptr(), c.data_ptr(), M, d, F, _stream()),
+              "gww_mlp_fused_bf16")
+    return c[:M], x_out
+
+
 def attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:
     """qkv [B, T, 3 d] (q pre-scaled) -> ctx [B, T, d]; bf16 or fp32."""
     bf = qkv.dtype == torch.bfloat16

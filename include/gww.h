@@ -208,6 +208,17 @@ int gww_ln_fold_weights(const float* w, const float* ln_w, const float* ln_b, co
  * [M,N] with rows allocated up to the next multiple of 128; epilogue 0 (bias) or 1 (GELU). */
 int gww_gemm_fulln_bf16(const void* A, const void* W, const float* bias, void* C, long M, int N, int K,
                         int epilogue, void* stream);
+/* Fused MLP block at d_model = 384 (HF:modeling_whisper.py:401-407, residual add deferred to the consumer):
+ *   x_out = x + delta;   C = bf16( fc2( gelu( fc1( LayerNorm(x_out) ) ) ) + b2 )
+ * x fp32 [M,384], delta bf16 [M,384], x_out fp32 [M,384] (must not alias x); ln_u / ln_cb [F] from
+ * gww_ln_fold_weights of fc1; Wt = gww_mlp_pack_bf16 of the folded fc1 panel and the fc2 panel; C bf16 with rows
+ * allocated up to the next multiple of 128.  F % 128 == 0, F <= 1536.  The [M,F] activation never leaves the CU;
+ * GELU is x * sigmoid(odd quintic), |err| <= 2.6e-5 against the erf form. */
+int gww_mlp_fused_bf16(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
+                       const void* Wt, const float* b2, void* C, long M, int d, int F, void* stream);
+/* Pre-tile the weights of gww_mlp_fused_bf16: w1_folded bf16 [F,384] (gww_ln_fold_weights), w2 bf16 [384,F]
+ * -> out bf16, 2*384*F elements, as the sequence of swizzled 16-KiB LDS images the kernel streams. */
+int gww_mlp_pack_bf16(const void* w1_folded, const void* w2, void* out, int d, int F, void* stream);
 int gww_gemm_f32(const float* A, const float* W, const float* bias, const float* resid, float* C,
                  long M, int N, int K, int epilogue, void* stream);
 /* softmax(q k^T) v per head, q pre-scaled; qkv [B,T,3*d] (q|k|v), ctx [B,T,d]; head_dim 64 */

@@ -301,3 +301,57 @@ def test_dora_merge(T, gww, d_out, d_in, r):
     A0, B0, m0 = synth.dora_adapter(d_out, d_in, r, W0, seed=3, trained=False)
     got0 = ops.dora_merge(*(T.from_numpy(t).cuda() for t in (W0, A0, B0, m0)), s)
     np.testing.assert_allclose(got0.cpu().numpy(), W0, atol=1e-6, rtol=1e-6)
+
+
+def test_mlp_pack_layout(T, gww):
+    """Tile stream of the fused MLP: fc1 tiles are plain swizzled copies; fc2 tiles carry k with bits 2 / 3
+    swapped inside every 16-group."""
+    from gw_whisper_amd import ops
+    F, d = 256, 384
+    w1 = T.arange(F * d, dtype=T.float32).reshape(F, d).remainder(251).cuda().bfloat16()
+    w2 = (T.arange(d * F, dtype=T.float32).reshape(d, F).remainder(241) + 0.5).cuda().bfloat16()
+    out = ops.mlp_pack(w1, w2).float().cpu().numpy().reshape(F // 128, 12, 128, 8, 8)
+    w1n, w2n = w1.float().cpu().numpy(), w2.float().cpu().numpy()
+    k = np.arange(64)
+    sw = (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)
+    for c in range(F // 128):
+        for idx in range(12):
+            for row in (0, 1, 2, 77, 127):
+                img = out[c, idx, row]                       # [stored chunk][8]
+                logical = np.stack([img[ch ^ ((row >> 1) & 7)] for ch in range(8)]).reshape(64)
+                if idx < 6:
+                    ref = w1n[128 * c + row, 64 * idx:64 * idx + 64]
+                else:
+                    kh, ng = divmod(idx - 6, 3)
+                    ref = w2n[128 * ng + row, 128 * c + 64 * kh:128 * c + 64 * kh + 64][sw]
+                np.testing.assert_array_equal(logical, ref)
+
+
+@pytest.mark.parametrize("M,F", [(128, 128), (1500, 1536), (777, 512), (4000, 1536), (70000, 1536)])
+def test_mlp_fused(T, gww, M, F):
+    """LayerNorm -> fc1 -> GELU -> fc2 of (x + delta) in one kernel (mlp_fused.hip) against fp64:
+    HF:modeling_whisper.py:401-407 without the residual add (deferred to the consumer)."""
+    from gw_whisper_amd import ops
+    d = 384
+    rng = np.random.default_rng(M + F)
+    x = (rng.standard_normal((M, d)) * 2 + 0.3).astype(np.float32)
+    x[::7] += 25.0
+    dl = _bf(rng.standard_normal((M, d)) * 0.5)
+    lw = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    lb = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    w1 = (rng.standard_normal((F, d)) / np.sqrt(d)).astype(np.float32)
+    b1 = rng.standard_normal(F).astype(np.float32)
+    w2 = (rng.standard_normal((d, F)) / np.sqrt(F)).astype(np.float32)
+    b2 = rng.standard_normal(d).astype(np.float32)
+    xn = x + dl
+    h = oenc.gelu(oenc.layer_norm(xn.astype(np.float64), lw, lb) @ w1.astype(np.float64).T + b1)
+    ref = h @ _bf(w2).astype(np.float64).T + b2
+    c = lambda a: T.from_numpy(np.asarray(a)).cuda()
+    w1f, u, cb = ops.ln_fold_weights(c(w1), c(lw), c(lb), c(b1))
+    wt = ops.mlp_pack(w1f, c(w2).bfloat16())
+    out, x_new = ops.mlp_fused(c(x), c(dl).bfloat16(), wt, u, cb, c(b2))
+    np.testing.assert_array_equal(x_new.cpu().numpy(), xn.astype(np.float32))
+    got = out.float().cpu().numpy()
+    # bf16 operands twice (K = 384, then K = F) + bf16 output
+    np.testing.assert_allclose(got, ref, atol=4e-2, rtol=2 ** -7)
+    assert np.sqrt(((got - ref) ** 2).mean()) < 8e-3

@@ -1,1 +1,2 @@
-timeout -k 10 1100 python -m pytest tests -q -m gpu 2>&1 | grep -v "^$" > gpurun_out/t1.log; grep -n "FAILED\|passed\|failed" gpurun_out/t1.log | head -40
+set -o pipefail
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-train > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; python tools/show_bench.py gpurun_out/bench.json

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
 import json, sys
-d = json.loads(sys.stdin.read())
+d = json.loads(open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read())
 print(f"value {d['value']:.0f} seg/s  ms/step {d['ms_per_step']:.3f}  frac {d['forward']['frac_of_bf16_mfma_peak']:.4f}")
 print("  ".join(f"{r['kernel']}={r['ms_per_launch']:.3f}" for r in d.get("kernels", [])))
