@@ -31,10 +31,9 @@ __device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((
 __device__ __forceinline__ int v_off(int row, int colbyte) { return row * 128 + (colbyte ^ (((row >> 1) & 1) << 6)); }
 
 __device__ __forceinline__ bf16x8 cvt8(const f32x16& a, int base) {
-  bf16x8 r;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[base + j];
-  return r;
+  const u32x4 r = {pack2bf(a[base], a[base + 1]), pack2bf(a[base + 2], a[base + 3]),
+                   pack2bf(a[base + 4], a[base + 5]), pack2bf(a[base + 6], a[base + 7])};
+  return __builtin_bit_cast(bf16x8, r);
 }
 
 __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short* __restrict__ qkv,

@@ -49,8 +49,12 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 __device__ __forceinline__ float bf2f(unsigned short u) {
   return __builtin_bit_cast(float, ((unsigned int)u) << 16);
 }
+// two values -> one dword, ONE v_cvt_pk_bf16_f32 (the scalar casts above cost three instructions per pair)
 __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
-  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

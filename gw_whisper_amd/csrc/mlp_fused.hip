@@ -120,18 +120,18 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lane_off = (unsigned)lane * 16u;
   const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr)lds;
-  auto issue_piece = [&](int c, int idx, int stage, int j) {
+  auto issue_piece = [&](int tile, int stage, int j) {
     const unsigned dst = lds_base + (unsigned)(stage * MF_TILE + (MF_GL * wave_u + j) * 1024);
-    const unsigned short* src = Wt + ((long)(c * MF_TPC + idx) * (MF_TILE / 2) + (MF_GL * wave_u + j) * 512);
+    const unsigned short* src = Wt + ((long)tile * (MF_TILE / 2) + (MF_GL * wave_u + j) * 512);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(lane_off), "s"(src), "s"(dst)
                  : "memory");
   };
-  auto issue = [&](int c, int idx, int stage) {
+  auto issue = [&](int tile, int stage) {
 #pragma unroll
-    for (int j = 0; j < MF_GL; ++j) issue_piece(c, idx, stage, j);
+    for (int j = 0; j < MF_GL; ++j) issue_piece(tile, stage, j);
   };
 
   MSTAMP_DECL
@@ -244,16 +244,17 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   mf_wait_vmcnt<0>();   // every ordinary load / store is retired before the ring starts counting
   MSTAMP(0);
 #pragma unroll
-  for (int p = 0; p < MF_AHEAD; ++p) issue(0, p, p);
+  for (int p = 0; p < MF_AHEAD; ++p) issue(p, p);
 
-  // per-lane LDS offsets of the W fragments inside a tile: row 32 t + r, 16-byte chunk index
-  //   fc1 tile, k-step j : chunk 4 hh + j      fc2 tile, k-step s : chunk 2 s + hh
-  int off1[4], off2[4];
+  // per-lane LDS offsets of the W fragments inside a tile
+  //   fc1 tile [64 n][128 k], 256-byte rows, 16-byte chunk c stored at c ^ (row & 15):
+  //     sub-tile tl (rows 32 tl + r), k-step (Sl, j) of the tile: chunk 8 Sl + 4 hh + j
+  //   fc2 tile [128 n2][64 k], 128-byte rows, chunk c stored at c ^ ((row >> 1) & 7): k-step s: chunk 2 s + hh
+  int off1[8], off2[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    off1[j] = r * 128 + (((4 * hh + j) ^ ((r >> 1) & 7)) << 4);
-    off2[j] = r * 128 + (((2 * j + hh) ^ ((r >> 1) & 7)) << 4);
-  }
+  for (int j = 0; j < 8; ++j) off1[j] = r * 256 + ((((j >> 2) * 8 + 4 * hh + (j & 3)) ^ (r & 15)) << 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) off2[j] = r * 128 + (((2 * j + hh) ^ ((r >> 1) & 7)) << 4);
 
   f32x16 sacc[4], oacc[MF_OT];
 #pragma unroll
@@ -284,43 +285,51 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     pf[t][cc >> 1][2 * (cc & 1) + 1] = pack2bf(a_v[slot][2], a_v[slot][3]);
     asm volatile("" : "+v"(pf[t][cc >> 1][2 * (cc & 1)]), "+v"(pf[t][cc >> 1][2 * (cc & 1) + 1]));
   };
-  // pieces riding in a step: p0 in gap 0, p1 (if any) in gap 2; the four values of a piece are independent
-  // chains (ILP 4 hides the v_exp / v_rcp latency); act_end pins the result here (hipcc would sink the whole
-  // computation to its first use, after the last fc2 k-half)
+  // the four values of a piece are independent chains (ILP 4 hides the v_exp / v_rcp latency); act_end pins
+  // the result here (hipcc would sink the whole computation to its first use)
   auto act_piece = [&](int slot, int c, int p) {
     act_begin(slot, c, p);
     act_val(slot, p, 0); act_val(slot, p, 1); act_val(slot, p, 2); act_val(slot, p, 3);
     act_end(slot, p);
-  };
-  auto act_gap = [&](int c, int p0, int p1, int u) {
-    if (u == 0 && p0 >= 0) act_piece(0, c, p0);
-    if (u == 2 && p1 >= 0) act_piece(1, c, p1);
   };
 
   // tile 0 landed (younger tiles may still be in flight)
   mf_wait_vmcnt<MF_GL*(MF_AHEAD - 1)>();
   __builtin_amdgcn_s_barrier();
 
-  // W fragments are read one step (4 MFMAs) ahead of their use, across tile boundaries too: the waits
-  // below run one tile ahead, so tile it + 1 is complete and visible while tile it is being computed.
-  // Inside a step every MFMA is followed by its share of the other work (one fragment read, one DMA piece,
-  // a slice of GELU): those issue while the MFMA runs instead of after the group of four.
+  // Schedule of one ffn chunk (12 tiles, 4 steps of 4 MFMAs each):
+  //   idx 0..2  fc1, n-half 0 (S[0], S[1]), k-thirds 0..2
+  //   idx 3..5  fc1, n-half 1 (S[2], S[3])                  + GELU pieces 0..7  (S[0], S[1] are final)
+  //   idx 6..8  fc2, k-half 0 (P from S[0], S[1]), ng 0..2  + GELU pieces 8..15 (S[2], S[3] are final)
+  //   idx 9..11 fc2, k-half 1 (P from S[2], S[3]), ng 0..2
+  // W fragments are read one step ahead of their use, across tile boundaries too (the ring waits run one
+  // tile ahead, so tile it + 1 is complete and visible while tile it is being computed).  Every step holds
+  // 4 MFMAs, the 4 fragment reads of the next step, one DMA piece and at most one GELU piece, interleaved by
+  // sched_group_barrier so that the VALU work issues in the shadow of the MFMAs.
   bf16x8 wf[2][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) wf[0][t] = *reinterpret_cast<const bf16x8*>(lds + t * 4096 + off1[0]);
+  for (int t = 0; t < 4; ++t)
+    wf[0][t] = *reinterpret_cast<const bf16x8*>(lds + (t & 1) * 8192 + off1[t >> 1]);
 
+  // fragment u of step (idx, sub) inside its tile: byte offset
+  auto frag_off = [&](int idx, int sub, int u) -> int {
+    if (idx < MF_KT) return (u & 1) * 8192 + off1[2 * sub + (u >> 1)];   // (tl = u & 1, k-step 2 sub + (u >> 1))
+    return u * 4096 + off2[sub];
+  };
+
+  const int total = nch * MF_TPC;
   int stage = 0;   // ring stage of the tile being computed
   for (int c = 0; c < nch; ++c) {
 #pragma unroll
     for (int idx = 0; idx < MF_TPC; ++idx) {
       // tile it = 12 c + idx.  Wait for tile it + 1; the barrier also says every wave is done with tile
-      // it - 1, whose stage receives tile it + MF_AHEAD.
-      if (c == nch - 1 && idx >= MF_TPC - (MF_AHEAD - 1)) mf_wait_vmcnt<0>();
-      else mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
+      // it - 1, whose stage receives tile it + MF_AHEAD (past the end: a harmless re-read of the last tile,
+      // so that the counted wait is the same in every iteration).
+      mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
       __builtin_amdgcn_s_barrier();
       MSTAMP(1);
-      const int dma_idx = idx + MF_AHEAD < MF_TPC ? idx + MF_AHEAD : idx + MF_AHEAD - MF_TPC;
-      const int dma_c = idx + MF_AHEAD < MF_TPC ? c : c + 1;
+      const int it = c * MF_TPC + idx;
+      const int dma_tile = it + MF_AHEAD < total ? it + MF_AHEAD : total - 1;
       const int dma_stage = stage + MF_AHEAD >= MF_NST ? stage + MF_AHEAD - MF_NST : stage + MF_AHEAD;
       const int stage_next = stage + 1 == MF_NST ? 0 : stage + 1;
       MSTAMP(2);
@@ -331,51 +340,74 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         bf16x8(&nxt)[4] = wf[(q + 1) & 1];
         const int nidx = sub == 3 ? (idx + 1 == MF_TPC ? 0 : idx + 1) : idx;
         const int nsub = (sub + 1) & 3;
-        const unsigned char* Wn = lds + (sub == 3 ? stage_next : stage) * MF_TILE + (nidx < MF_KT ? off1[nsub] : off2[nsub]);
-        // activation pieces riding in this step
-        int p0 = -1, p1 = -1;
-        if (idx == MF_KT - 1 && sub == 3) { p0 = 0; p1 = 1; }          // S[0] is final after this step's first MFMA
-        if (idx >= MF_KT) {
-          const int q2 = 4 * (idx - MF_KT) + sub;                       // 0 .. 23 over the six fc2 tiles
-          if (q2 < 3) { p0 = 2 + 2 * q2; p1 = 3 + 2 * q2; }
-          else if (q2 < 11) p0 = 5 + q2;
+        const unsigned char* Wn = lds + (sub == 3 ? stage_next : stage) * MF_TILE;
+        // GELU piece riding in this step: two steps out of three in tiles 3..8
+        int piece = -1;
+        if (idx >= 3 && idx < 9) {
+          const int qq = 4 * (idx - 3) + sub;          // 0 .. 23
+          if (qq % 3 != 2) piece = qq - qq / 3;         // 0 .. 15
         }
-        const int i2 = idx - MF_KT, kh = i2 / 3, ng = i2 - 3 * kh;
         __builtin_amdgcn_sched_barrier(0);
+        if (!(GWW_MF_EXP & 1)) issue_piece(dma_tile, dma_stage, sub);
+        if (piece >= 0) act_piece(0, c, piece);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (idx < MF_KT) {
-            // ---- fc1: S[u] (+)= W1' tile (rows 32 u ..) . a[k-tile idx, k-step sub]
-            if (idx == 0 && sub == 0) {
+            // ---- fc1: S[2 nh + tl] (+)= W1' tile rows 32 tl .. . a[k-step]
+            const int nh = idx / 3, kt3 = idx - 3 * nh, tl = u & 1;
+            const int ks = 2 * sub + (u >> 1);                      // k-step of the tile, 0 .. 7
+            const int afi = 4 * (2 * kt3 + (ks >> 2)) + (ks & 3);   // af[4 S + j]
+            if (kt3 == 0 && ks == 0) {
               f32x16 z;
 #pragma unroll
               for (int j = 0; j < 16; ++j) z[j] = 0.f;
-              sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[u], af[4 * idx + sub], z, 0, 0, 0);
+              sacc[2 * nh + tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[u], af[afi], z, 0, 0, 0);
             } else {
-              sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[u], af[4 * idx + sub], sacc[u], 0, 0, 0);
+              sacc[2 * nh + tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[u], af[afi], sacc[2 * nh + tl], 0, 0, 0);
             }
           } else {
             // ---- fc2: O[4 ng + u] += W2 tile (rows 32 u ..) . P[k-step]
+            const int i2 = idx - MF_KT, kh = i2 / 3, ng = i2 - 3 * kh;
             oacc[4 * ng + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                 cur[u], __builtin_bit_cast(bf16x8, pf[2 * kh + (sub >> 1)][sub & 1]), oacc[4 * ng + u], 0, 0, 0);
           }
-          __builtin_amdgcn_sched_barrier(0);
-          if (!(GWW_MF_EXP & 4)) nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + u * 4096);
-          if (u == 0 && !(GWW_MF_EXP & 1) && dma_c < nch) issue_piece(dma_c, dma_idx, dma_stage, sub);
-          if (idx == MF_KT - 1 && sub == 3) {
-            // pieces 0 and 1 (both of S[0]) wait for the first MFMA of this step: gaps 2 and 3
-            if (u == 2) act_piece(0, c, 0);
-            if (u == 3) act_piece(1, c, 1);
-          } else {
-            act_gap(c, p0, p1, u);
-          }
-          __builtin_amdgcn_sched_barrier(0);
+          if (!(GWW_MF_EXP & 4)) nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + frag_off(nidx, nsub, u));
         }
+        // pipeline of the step: MFMA, fragment read, a slice of the VALU work -- four times
+        if (piece >= 0) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // DS read: fragment + u / cb of the piece
+          __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);  // VALU
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       stage = stage_next;
       MSTAMP(8 + idx);
     }
   }
+  mf_wait_vmcnt<0>();   // the re-reads issued past the end
 
   // ---- epilogue: + b2 -> bf16 -> wave-private LDS transpose -> whole-line stores
 #pragma unroll
@@ -404,9 +436,11 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 }
 
 // Pre-tile the two weight panels of the block into the stream k_mlp_fused consumes:
-//   out[c][idx] = one 16-KiB LDS image [128 rows][64 k], 16-byte chunks XOR-swizzled by (row >> 1) & 7
-//   idx < 6 : W1'[128 c + row][64 idx + k]                                   (gain-folded fc1, [F, 384])
-//   idx >= 6: i2 = idx - 6, kh = i2 / 3, ng = i2 % 3: W2[128 ng + row][128 c + 64 kh + swap23(k)]
+//   out[c][idx] = one 16-KiB LDS image
+//   idx < 6 : nh = idx / 3, kt3 = idx % 3: [64 rows][128 k] = W1'[128 c + 64 nh + row][128 kt3 + k] (gain-folded
+//             fc1, [F, 384]); 16-byte chunks XOR-swizzled by row & 15
+//   idx >= 6: i2 = idx - 6, kh = i2 / 3, ng = i2 % 3: [128 rows][64 k] = W2[128 ng + row][128 c + 64 kh + swap23(k)];
+//             chunks XOR-swizzled by (row >> 1) & 7
 // swap23 exchanges bits 2 and 3 of k: the operand order of the accumulator-as-operand product (header).
 __global__ __launch_bounds__(256) void k_mlp_pack(const unsigned short* __restrict__ w1,
                                                   const unsigned short* __restrict__ w2,
@@ -417,7 +451,10 @@ __global__ __launch_bounds__(256) void k_mlp_pack(const unsigned short* __restri
     const int c = tile / MF_TPC, idx = tile - c * MF_TPC;
     u32x4 v;
     if (idx < MF_KT) {
-      v = *reinterpret_cast<const u32x4*>(w1 + (long)(128 * c + row) * MF_D + 64 * idx + 8 * chunk);
+      // [64 n][128 k] image: 16 chunks per row, chunk ch stored at ch ^ (row & 15)
+      const int row2 = within >> 4, ch = (within & 15) ^ (row2 & 15);
+      const int nh = idx / 3, kt3 = idx - 3 * nh;
+      v = *reinterpret_cast<const u32x4*>(w1 + (long)(128 * c + 64 * nh + row2) * MF_D + 128 * kt3 + 8 * ch);
     } else {
       const int i2 = idx - MF_KT, kh = i2 / 3, ng = i2 - 3 * kh;
       const unsigned short* src = w2 + (long)(128 * ng + row) * F + 128 * c + 64 * kh;

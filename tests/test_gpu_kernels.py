@@ -304,27 +304,30 @@ def test_dora_merge(T, gww, d_out, d_in, r):
 
 
 def test_mlp_pack_layout(T, gww):
-    """Tile stream of the fused MLP: fc1 tiles are plain swizzled copies; fc2 tiles carry k with bits 2 / 3
-    swapped inside every 16-group."""
+    """Tile stream of the fused MLP: fc1 tiles are swizzled [64 n][128 k] images; fc2 tiles [128 n][64 k]
+    carry k with bits 2 / 3 swapped inside every 16-group."""
     from gw_whisper_amd import ops
     F, d = 256, 384
     w1 = T.arange(F * d, dtype=T.float32).reshape(F, d).remainder(251).cuda().bfloat16()
     w2 = (T.arange(d * F, dtype=T.float32).reshape(d, F).remainder(241) + 0.5).cuda().bfloat16()
-    out = ops.mlp_pack(w1, w2).float().cpu().numpy().reshape(F // 128, 12, 128, 8, 8)
+    out = ops.mlp_pack(w1, w2).float().cpu().numpy().reshape(F // 128, 12, 8192)
     w1n, w2n = w1.float().cpu().numpy(), w2.float().cpu().numpy()
     k = np.arange(64)
     sw = (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)
     for c in range(F // 128):
         for idx in range(12):
-            for row in (0, 1, 2, 77, 127):
-                img = out[c, idx, row]                       # [stored chunk][8]
-                logical = np.stack([img[ch ^ ((row >> 1) & 7)] for ch in range(8)]).reshape(64)
-                if idx < 6:
-                    ref = w1n[128 * c + row, 64 * idx:64 * idx + 64]
-                else:
-                    kh, ng = divmod(idx - 6, 3)
-                    ref = w2n[128 * ng + row, 128 * c + 64 * kh:128 * c + 64 * kh + 64][sw]
-                np.testing.assert_array_equal(logical, ref)
+            if idx < 6:      # fc1: [64 n][128 k], chunk ^ (row & 15)
+                img = out[c, idx].reshape(64, 16, 8)
+                nh, kt3 = divmod(idx, 3)
+                for row in (0, 1, 17, 63):
+                    logical = np.stack([img[row, ch ^ (row & 15)] for ch in range(16)]).reshape(128)
+                    np.testing.assert_array_equal(logical, w1n[128 * c + 64 * nh + row, 128 * kt3:128 * kt3 + 128])
+            else:            # fc2: [128 n2][64 k], chunk ^ ((row >> 1) & 7), k with bits 2 / 3 swapped
+                img = out[c, idx].reshape(128, 8, 8)
+                kh, ng = divmod(idx - 6, 3)
+                for row in (0, 1, 2, 77, 127):
+                    logical = np.stack([img[row, ch ^ ((row >> 1) & 7)] for ch in range(8)]).reshape(64)
+                    np.testing.assert_array_equal(logical, w2n[128 * ng + row, 128 * c + 64 * kh:128 * c + 64 * kh + 64][sw])
 
 
 @pytest.mark.parametrize("M,F", [(128, 128), (1500, 1536), (777, 512), (4000, 1536), (70000, 1536)])
