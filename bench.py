@@ -252,18 +252,28 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
-        if trace:
-            # hipEvents on the launch stream around every kernel of the TIMED steps (about 30 event
-            # records per forward, a few tens of microseconds per step)
-            enc.trace_enable(True)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
         barrier()
         dt = time.perf_counter() - t0
-        traced = enc.trace_read() if trace else {}
-        enc.trace_enable(False)
+        traced = {}
+        if trace:
+            # Per-kernel durations for the roofline: a SEPARATE pass of the same K steps on ONE stream
+            # (hipEvents on the launch stream around every kernel).  In the timed region above every launch
+            # of a two-stream run shares the CUs with the other half batch's kernel, so its duration is not
+            # its own; here each launch covers the whole batch and owns the GPU.
+            if args.split:
+                enc.set_split(False)
+            step()
+            enc.trace_enable(True)
+            for _ in range(args.steps):
+                out = step()
+            traced = enc.trace_read()
+            enc.trace_enable(False)
+            if args.split:
+                enc.set_split(True)
     assert torch.isfinite(out[1]).all()
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -322,12 +332,12 @@ def main():
                     continue
                 per = ms / cnt
                 flops, byts = work[name]
-                if args.split and B >= 64:      # each launch covers one half batch
-                    flops, byts = flops * (B // 2) / B, byts * (B // 2) / B
                 rows.append({"kernel": name, "launches_per_step": cnt / args.steps, "ms_per_launch": per,
                              "ms_per_step": ms / args.steps, "tflops": flops / per / 1e9 if flops else None,
                              "algorithmic_gbs": byts / per / 1e6})
             line["kernels"] = rows
+            line["kernels_note"] = ("single-stream pass of the same steps after the timed region: whole-batch launches, "
+                                    "each owning the GPU (HIP events on the launch stream)")
             dom = max(rows, key=lambda r: r["ms_per_step"])
             if dom["tflops"]:
                 line["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
