@@ -20,6 +20,8 @@
 // fp32 kernel: same dataflow on v_mfma_f32_32x32x2_f32 (exact fp32), 32-key tiles.
 #include "common.h"
 
+#include <type_traits>
+
 namespace gww {
 
 constexpr int DH = 64;
@@ -46,8 +48,13 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
   auto Vs = [&](int buf) -> unsigned char* { return lds + (2 + buf) * TILE_BYTES; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qt = blockIdx.x % q_tiles;
-  const int bh = blockIdx.x / q_tiles;
+  // XCD-aware work order: workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Give every
+  // XCD a contiguous range of (b, h, q-tile) so that the q-tiles of one head -- which all stream the same
+  // K / V (384 KB) -- run on ONE XCD back to back and K / V come from HBM once instead of once per XCD.
+  const unsigned nblk = gridDim.x, per = nblk >> 3;
+  const unsigned wid = blockIdx.x < 8 * per ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
+  const int qt = wid % q_tiles;
+  const int bh = wid / q_tiles;
   const int b = bh / H, h = bh - b * H;
   const int d = H * DH;
   const long row_stride = 3L * d;
@@ -109,7 +116,13 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
   const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
   const int tr_colbyte = (((lane & 31) >> 4) * 16 + 4 * tr_p) * 2;
 
-  for (int kt = 0; kt < n_kt; ++kt) {
+  // one key tile; MASKED (compile time) only for the ragged last tile, so the full tiles carry no per-score
+  // select.  The running maximum is refreshed only when some row's tile maximum exceeds it by more than
+  // kDefer (any reference value is exact algebra; p <= e^kDefer keeps bf16 / fp32 far from overflow): the
+  // 16 rescale multiplies of O and the extra exp leave most tiles.
+  constexpr float kDefer = 8.0f;
+  auto tile = [&](int kt, auto masked_c) {
+    constexpr bool MASKED = decltype(masked_c)::value;
     const int buf = kt & 1;
     if (kt + 1 < n_kt) gload(kt + 1);
 
@@ -125,8 +138,7 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
         st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[g], 0, 0, 0);
       }
     }
-    // ---- mask keys >= T (last tile only)
-    if (kt == n_kt - 1 && (T % KB) != 0) {
+    if constexpr (MASKED) {   // keys >= T
 #pragma unroll
       for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -142,9 +154,17 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
 #pragma unroll
       for (int j = 0; j < 16; ++j) tmax = fmaxf(tmax, st[g][j]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
-    const float ms = m_new * kLog2e;
+    if (__builtin_amdgcn_ballot_w64(tmax > m_run + kDefer) != 0) {   // wave-uniform
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ot[n][j] *= alpha;
+    }
+    const float ms = m_run * kLog2e;
     float psum = 0.f;
 #pragma unroll
     for (int g = 0; g < 2; ++g)
@@ -154,12 +174,7 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
         st[g][j] = p;
         psum += p;
       }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) ot[n][j] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T P^T : B operand = bf16(st) registers 8 s .. 8 s + 7 (k-step s);
     //      A operand element j <-> key 32 g + 16 s + 8 (j>>2) + 4 hh + (j&3), dh = 32 n + r
@@ -186,7 +201,10 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
     }
     if (kt + 1 < n_kt) lstore(buf ^ 1);
     __syncthreads();
-  }
+  };
+  for (int kt = 0; kt + 1 < n_kt; ++kt) tile(kt, std::false_type{});
+  if ((T % KB) != 0) tile(n_kt - 1, std::true_type{});
+  else tile(n_kt - 1, std::false_type{});
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   // same moment and idles HBM during the MFMA phase.
   if (stagger_ticks > 0 && blockIdx.x < 256) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 7) * stagger_ticks;
+    const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 15) * stagger_ticks;
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
   }
 
