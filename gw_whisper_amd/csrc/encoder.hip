@@ -26,6 +26,9 @@ int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int dy_f32
                   void* dx_bf16, long M, int d, hipStream_t s);
 int launch_gelu_bf16(const void* z, const void* df, void* out, long n, hipStream_t s);
 int launch_sub_f32_bf16(const float* a, const float* b, void* out, long n, hipStream_t s);
+int launch_stem_dz2(const void* dxb, const void* z2, void* out, int B, int T, int d, hipStream_t s);
+int launch_stem_dz1(const void* col, const void* z1, void* out, int B, int T, int Tin, int d, hipStream_t s);
+int launch_stem_dmel(const void* col1, float* dmel, int B, int Tin, int C, int Kp, hipStream_t s);
 int launch_mlp_pack(const void* w1_folded, const void* w2, void* out, int d, int F, hipStream_t s);
 int launch_mlp_fused(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
                      const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s);
@@ -80,6 +83,7 @@ struct gww_encoder {
   char* blob = nullptr;
   size_t blob_bytes = 0;
   unsigned short *c1w = nullptr, *c2w = nullptr;
+  unsigned short *c1wT = nullptr, *c2wT = nullptr;   // [Kpad, d] / [3 d, d]: input-gradient GEMMs of the stem
   float *c1w32 = nullptr, *c2w32 = nullptr;
   float *c1b = nullptr, *c2b = nullptr, *pos = nullptr, *lnw = nullptr, *lnb = nullptr;
   std::vector<LayerW> layers;
@@ -102,6 +106,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
   const size_t o_c1w = take((size_t)d * kConv1Kpad * 2), o_c2w = take((size_t)d * 3 * d * 2);
   const size_t o_c1w32 = take((size_t)d * kConv1Kpad * 4), o_c2w32 = take((size_t)d * 3 * d * 4);
+  const size_t o_c1wT = take((size_t)d * kConv1Kpad * 2), o_c2wT = take((size_t)d * 3 * d * 2);
   const size_t o_c1b = take(d * 4), o_c2b = take(d * 4), o_pos = take((size_t)T * d * 4);
   const size_t o_lnw = take(d * 4), o_lnb = take(d * 4);
   struct LO { size_t wqkv, wo, w1, w2, wqkv32, wo32, w132, w232, bqkv, bo, b1, b2, ln1w, ln1b, ln2w, ln2b,
@@ -145,6 +150,8 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
   char* p = e->blob;
   e->c1w = (unsigned short*)(p + o_c1w);
   e->c2w = (unsigned short*)(p + o_c2w);
+  e->c1wT = (unsigned short*)(p + o_c1wT);
+  e->c2wT = (unsigned short*)(p + o_c2wT);
   e->c1w32 = (float*)(p + o_c1w32);
   e->c2w32 = (float*)(p + o_c2w32);
   e->c1b = (float*)(p + o_c1b);
@@ -255,6 +262,8 @@ extern "C" int gww_encoder_set_weights(gww_encoder* e, const gww_enc_globals* g,
   };
   GWW_TRY(pack(g->conv1_w, e->c1w, e->c1w32, d, C, 3, kConv1Kpad, 1.f));
   GWW_TRY(pack(g->conv2_w, e->c2w, e->c2w32, d, d, 3, 3 * d, 1.f));
+  GWW_TRY(launch_transpose_bf16(e->c1w, e->c1wT, d, kConv1Kpad, s));
+  GWW_TRY(launch_transpose_bf16(e->c2w, e->c2wT, d, 3 * d, s));
   GWW_TRY(launch_scale_copy(g->conv1_b, e->c1b, d, 1.f, s));
   GWW_TRY(launch_scale_copy(g->conv2_b, e->c2b, d, 1.f, s));
   GWW_HIP(hipMemcpyAsync(e->pos, g->pos, (size_t)T * d * 4, hipMemcpyDeviceToDevice, s));
@@ -553,7 +562,7 @@ SavedLayout saved_layout(const gww_enc_cfg& c, int B) {
   return s;
 }
 struct TrainWs {
-  size_t melT, c1, h2, f1, dx, dxb, dbig, dh, dctx, dqkv, Dv, total;
+  size_t melT, c1, h2, f1, dx, dxb, dbig, dh, dctx, dqkv, Dv, z1, col1, total;
 };
 TrainWs train_ws(const gww_enc_cfg& c, int B) {
   const size_t d = c.d_model, F = c.ffn, Tin = c.t_in, T = c.t_in / 2, C = c.n_mels, H = c.n_heads;
@@ -572,6 +581,8 @@ TrainWs train_ws(const gww_enc_cfg& c, int B) {
   w.dctx = take(Mp * d * 2);
   w.dqkv = take(Mp * 3 * d * 2);
   w.Dv = take((size_t)B * H * T * 4);
+  w.z1 = take(((size_t)B * (Tin + 2) + 256) * d * 2);            // stem backward: conv1 pre-activation / its gradient
+  w.col1 = take(((size_t)B * (Tin + 2) + 256) * kConv1Kpad * 2); // stem backward: conv1 taps side by side
   w.total = off;
   return w;
 }
@@ -639,11 +650,13 @@ extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int b
 // d_last_hidden: fp32 [B*T, d] gradient of the loss w.r.t. last_hidden_state.
 // targets: DoRA-adapted projections whose A / B / magnitude gradients are wanted; the gradient buffers
 // are ACCUMULATED into (zero them once per step).  d_x0 (optional, fp32 [B*T, d]): gradient w.r.t. the
-// residual stream entering layer 0 (the conv stem output).
+// residual stream entering layer 0 (the conv stem output).  d_mel (optional, fp32 [B, n_mels, t_in]): gradient
+// w.r.t. the input features, through the conv stem (MLGWSC-1/train.py:494-504 trains its Q-adapter through
+// the frozen encoder).
 extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* workspace, size_t workspace_bytes,
                                           const void* saved, size_t saved_bytes, const float* d_last_hidden,
                                           const gww_dora_target* targets, int n_targets, float* d_x0,
-                                          void* stream) {
+                                          float* d_mel, void* stream) {
   GWW_REQUIRE(e && workspace && saved && d_last_hidden, "gww_encoder_train_backward: NULL argument");
   GWW_REQUIRE(batch > 0 && n_targets >= 0 && (n_targets == 0 || targets), "gww_encoder_train_backward: bad argument");
   const SavedLayout sl = saved_layout(e->cfg, batch);
@@ -713,5 +726,23 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
     GWW_TRY(launch_ln_bwd(x_in(l), W.ln1w, dh, 0, dx, 1, dxb, M, d, s));
   }
   if (d_x0) GWW_HIP(hipMemcpyAsync(d_x0, dx, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
+  if (d_mel) {
+    // ---- conv stem backward: x0 = gelu(conv2(gelu(conv1(mel)))) + pos (melT and c1 of the forward are still
+    // in the workspace); the pre-activations are recomputed by the same GEMMs with a plain bias epilogue
+    const int Tin = e->cfg.t_in, C = e->cfg.n_mels;
+    GWW_REQUIRE(B <= 512, "gww_encoder_train_backward: d_mel supports batch <= 512");
+    const void* melT = base + w.melT;
+    const void* c1 = base + w.c1;
+    void* z1 = base + w.z1;
+    void* col1 = base + w.col1;
+    const long M2 = (long)B * (T + 1), M1 = (long)B * (Tin + 2);
+    GWW_TRY(launch_gemm_bf16(c1, 2L * d, e->c2w, e->c2b, nullptr, nullptr, dh, M2, d, 3 * d, EPI_BIAS, 0, s, 0));       // z2
+    GWW_TRY(launch_stem_dz2(dxb, dh, dctx, B, T, d, s));                                                              // dz2
+    GWW_TRY(launch_gemm_bf16(dctx, d, e->c2wT, nullptr, nullptr, nullptr, dqkv, M2, 3 * d, d, EPI_BIAS, 0, s, 0));     // col
+    GWW_TRY(launch_gemm_bf16(melT, C, e->c1w, e->c1b, nullptr, nullptr, z1, M1, d, kConv1Kpad, EPI_BIAS, 0, s, 0));    // z1
+    GWW_TRY(launch_stem_dz1(dqkv, z1, z1, B, T, Tin, d, s));                                                          // dz1
+    GWW_TRY(launch_gemm_bf16(z1, d, e->c1wT, nullptr, nullptr, nullptr, col1, M1, kConv1Kpad, d, EPI_BIAS, 0, s, 0));  // col1
+    GWW_TRY(launch_stem_dmel(col1, d_mel, B, Tin, C, kConv1Kpad, s));
+  }
   return GWW_OK;
 }

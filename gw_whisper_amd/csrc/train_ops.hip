@@ -161,6 +161,136 @@ int launch_transpose_bf16(const void* in, void* out, int R, int Cn, hipStream_t 
   return GWW_OK;
 }
 
+// ---------------------------------------------------------------- conv stem backward (gradient w.r.t. the mel input)
+// HF:modeling_whisper.py:618-619: x0 = gelu(conv2(gelu(conv1(mel)))) + pos.  Both convolutions run as GEMMs over
+// overlapping rows of token-major padded buffers (encoder.hip), so their input gradients are a GEMM against
+// the transposed panel ("col" rows = taps side by side) followed by a gather over the taps -- no atomics.
+__device__ __forceinline__ float gelu_grad(float z) {   // Phi(z) + z phi(z)
+  return 0.5f * (1.0f + erff(z * 0.70710678f)) + z * 0.3989422804f * __expf(-0.5f * z * z);
+}
+
+// dz2[b (T+1) + t] = t < T ? bf16(dx0[b T + t]) * gelu'(z2[b (T+1) + t]) : 0        (8 columns per thread)
+__global__ __launch_bounds__(256) void k_stem_dz2(const unsigned short* __restrict__ dxb,
+                                                  const unsigned short* __restrict__ z2,
+                                                  unsigned short* __restrict__ out, int T, int d8, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const long row = i / d8;
+    const int c8 = (int)(i - row * d8);
+    const long b = row / (T + 1);
+    const int t = (int)(row - b * (T + 1));
+    u32x4 o = {0u, 0u, 0u, 0u};
+    if (t < T) {
+      const u32x4 g = reinterpret_cast<const u32x4*>(dxb)[(b * T + t) * d8 + c8];
+      const u32x4 z = reinterpret_cast<const u32x4*>(z2)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = pack2bf(bf2f((unsigned short)(g[j] & 0xffff)) * gelu_grad(bf2f((unsigned short)(z[j] & 0xffff))),
+                       bf2f((unsigned short)(g[j] >> 16)) * gelu_grad(bf2f((unsigned short)(z[j] >> 16))));
+    }
+    reinterpret_cast<u32x4*>(out)[i] = o;
+  }
+}
+
+// conv2 (stride 2, taps k = 0..2 read padded row p = 2 t + k).  col [B (T+1), 3 d]: col[b, t][k d + ci] =
+// sum_co dz2[b, t, co] W2[co, ci, k].  Gather into the conv1 output row t1 (padded row p = t1 + 1), times
+// gelu'(z1):   p even: col[b, p/2][ci] (p/2 < T) + col[b, p/2 - 1][2 d + ci];   p odd: col[b, (p-1)/2][d + ci].
+// z1 / out rows: b (Tin + 2) + t1 (the unshifted conv1 GEMM rows); rows t1 >= Tin are zeroed.  In place (out == z1) ok.
+__global__ __launch_bounds__(256) void k_stem_dz1(const unsigned short* __restrict__ col,
+                                                  const unsigned short* z1, unsigned short* out, int T, int Tin,
+                                                  int d, long n8) {
+  const int d8 = d / 8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const long row = i / d8;
+    const int c8 = (int)(i - row * d8);
+    const long b = row / (Tin + 2);
+    const int t1 = (int)(row - b * (Tin + 2));
+    u32x4 o = {0u, 0u, 0u, 0u};
+    if (t1 < Tin) {
+      const int p = t1 + 1;
+      float g[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = 0.f;
+      auto add = [&](long crow, int tap) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(col + (crow * 3 + tap) * d + 8 * c8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          g[2 * j] += bf2f((unsigned short)(v[j] & 0xffff));
+          g[2 * j + 1] += bf2f((unsigned short)(v[j] >> 16));
+        }
+      };
+      if (p & 1) {
+        add(b * (T + 1) + (p - 1) / 2, 1);
+      } else {
+        if (p / 2 < T) add(b * (T + 1) + p / 2, 0);
+        add(b * (T + 1) + p / 2 - 1, 2);
+      }
+      const u32x4 z = reinterpret_cast<const u32x4*>(z1)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = pack2bf(g[2 * j] * gelu_grad(bf2f((unsigned short)(z[j] & 0xffff))),
+                       g[2 * j + 1] * gelu_grad(bf2f((unsigned short)(z[j] >> 16))));
+    }
+    reinterpret_cast<u32x4*>(out)[i] = o;
+  }
+}
+
+// conv1 (taps k read padded mel row p = t1 + k = time + 1).  col1 [B (Tin+2), Kp]: col1[b, t1][k C + c] =
+// sum_co dz1[b, t1, co] W1[co, c, k].   dmel[b, c, tau] = sum_k col1[b, tau + 1 - k][k C + c], 0 <= tau + 1 - k < Tin.
+// One workgroup = 64 time steps of one segment, staged through LDS so that both sides are coalesced.
+__global__ __launch_bounds__(256) void k_stem_dmel(const unsigned short* __restrict__ col1, float* __restrict__ dmel,
+                                                   int Tin, int C, int Kp) {
+  constexpr int TT = 64;
+  extern __shared__ unsigned short sm[];             // [TT + 2][3 C + 2]
+  const int ld = 3 * C + 2;
+  const int b = blockIdx.y, tau0 = blockIdx.x * TT;
+  for (int i = threadIdx.x; i < (TT + 2) * 3 * C; i += 256) {
+    const int rl = i / (3 * C), k = i - rl * 3 * C;
+    const int t1 = tau0 - 1 + rl;
+    sm[rl * ld + k] = (t1 >= 0 && t1 < Tin) ? col1[((long)b * (Tin + 2) + t1) * Kp + k] : (unsigned short)0;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C * TT; o += 256) {
+    const int c = o / TT, tl = o - c * TT;
+    const int tau = tau0 + tl;
+    if (tau >= Tin) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v += bf2f(sm[(tl + 2 - k) * ld + k * C + c]);   // row tau + 1 - k  ->  local tl + 2 - k
+    dmel[((long)b * C + c) * Tin + tau] = v;
+  }
+}
+
+int launch_stem_dz2(const void* dxb, const void* z2, void* out, int B, int T, int d, hipStream_t s) {
+  GWW_REQUIRE(d % 8 == 0, "stem_dz2: d must be a multiple of 8");
+  const long n8 = (long)B * (T + 1) * (d / 8);
+  long blocks = cdiv(n8, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_stem_dz2, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)dxb,
+                     (const unsigned short*)z2, (unsigned short*)out, T, d / 8, n8);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+int launch_stem_dz1(const void* col, const void* z1, void* out, int B, int T, int Tin, int d, hipStream_t s) {
+  GWW_REQUIRE(d % 8 == 0 && Tin == 2 * T, "stem_dz1: bad shape");
+  const long n8 = (long)B * (Tin + 2) * (d / 8);
+  long blocks = cdiv(n8, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_stem_dz1, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)col,
+                     (const unsigned short*)z1, (unsigned short*)out, T, Tin, d, n8);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+int launch_stem_dmel(const void* col1, float* dmel, int B, int Tin, int C, int Kp, hipStream_t s) {
+  GWW_REQUIRE(3 * C <= Kp, "stem_dmel: col1 row shorter than 3 taps");
+  const size_t lds = (size_t)(64 + 2) * (3 * C + 2) * 2;
+  hipLaunchKernelGGL(k_stem_dmel, dim3((unsigned)cdiv(Tin, 64), (unsigned)B), dim3(256), lds, s,
+                     (const unsigned short*)col1, dmel, Tin, C, Kp);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
 // ---------------------------------------------------------------- bf16(a - b) of two fp32 tensors
 // out_proj's output is never stored on its own (it is fused into the residual add): its DoRA magnitude
 // gradient needs y = x_mid - x_in, rebuilt here.

@@ -235,7 +235,8 @@ class WhisperEncoder(nn.Module):
         return {lib().gww_encoder_trace_class_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
 
     def forward(self, input_features, attention_mask=None, **kwargs):
-        if torch.is_grad_enabled() and self._has_trainable_adapters():
+        if torch.is_grad_enabled() and (self._has_trainable_adapters() or
+                                        (torch.is_tensor(input_features) and input_features.requires_grad)):
             # DoRA training step: HIP forward that keeps activations + HIP backward (training.py)
             from .training import encoder_train_forward
             self._check_input(input_features)

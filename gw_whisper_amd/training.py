@@ -58,6 +58,7 @@ class _EncoderTrain(torch.autograd.Function):
                   "gww_encoder_train_forward")
         ctx.enc, ctx.B, ctx.ws, ctx.saved = enc, B, ws, saved
         ctx.n_params = len(params)
+        ctx.mel_shape = tuple(x.shape)
         return hidden
 
     @staticmethod
@@ -78,21 +79,25 @@ class _EncoderTrain(torch.autograd.Function):
             grads.append((dA, dB, dm))
             arr[i] = _lib.DoraTarget(li, pid, mod.r, float(mod.scaling), A.data_ptr(), Bm.data_ptr(), mag.data_ptr(),
                                      nrm.data_ptr(), dA.data_ptr(), dB.data_ptr(), dm.data_ptr())
+        # gradient w.r.t. the input features (conv stem backward) only when autograd asks for it
+        d_mel = torch.empty(ctx.mel_shape, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         with torch.cuda.device(dev):
             check(lib().gww_encoder_train_backward(enc._ensure_handle(), B, ctx.ws.data_ptr(), ctx.ws.numel(),
                                                    ctx.saved.data_ptr(), ctx.saved.numel(), d_hidden.data_ptr(), arr,
-                                                   len(targets), None, torch.cuda.current_stream().cuda_stream),
+                                                   len(targets), None, d_mel.data_ptr() if d_mel is not None else None,
+                                                   torch.cuda.current_stream().cuda_stream),
                   "gww_encoder_train_backward")
         flat = []
         for dA, dB, dm in grads:
             flat += [dA, dB, dm]
         assert len(flat) == ctx.n_params
         ctx.ws = ctx.saved = None
-        return (None, None, *flat)
+        return (None, d_mel, *flat)
 
 
 def encoder_train_forward(encoder, mel: torch.Tensor) -> torch.Tensor:
-    """last_hidden_state [B, 1500, d] with autograd through the DoRA parameters."""
+    """last_hidden_state [B, 1500, d] with autograd through the DoRA parameters and, when ``mel.requires_grad``,
+    through the conv stem to the input features."""
     if encoder.precision != "bf16":
         raise _lib.GwwError("the training step is implemented for precision='bf16'")
     params = []

@@ -170,7 +170,12 @@ int gww_encoder_train_forward(gww_encoder* enc, const float* mel, int batch, voi
                               float* last_hidden, void* stream);
 int gww_encoder_train_backward(gww_encoder* enc, int batch, void* workspace, size_t workspace_bytes,
                                const void* saved, size_t saved_bytes, const float* d_last_hidden,
-                               const gww_dora_target* targets, int n_targets, float* d_x0, void* stream);
+                               const gww_dora_target* targets, int n_targets, float* d_x0, float* d_mel,
+                               void* stream);
+/* d_x0 (optional): fp32 [batch*T, d] gradient w.r.t. the conv-stem output.  d_mel (optional): fp32
+ * [batch, n_mels, t_in] gradient w.r.t. the input features through the conv stem -- the encoder call is
+ * differentiable w.r.t. its input, as MLGWSC-1/train.py:494-504 (trainable Q-adapter in front of the frozen
+ * encoder) requires. */
 
 /* --------------------------------------------------------------------------
  * Kernel-level entry points (used by the parity tests and by the Python

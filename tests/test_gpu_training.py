@@ -228,3 +228,40 @@ def test_whisper_small_dora_step_runs(T, gww):
     for n, p in peft.named_parameters():
         if "lora_" in n:
             assert p.grad is not None and T.isfinite(p.grad).all() and p.grad.abs().max() > 0, n
+
+
+def test_input_gradient_through_the_conv_stem(T, gww):
+    """The encoder call is differentiable w.r.t. its input features (MLGWSC-1/train.py:494-504 trains a Q-adapter
+    in front of the frozen encoder): d loss / d mel from the HIP backward (layers + conv stem) against central
+    finite differences of the fp64 oracle, no adapters involved."""
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    cfg = oenc.EncCfg(128, 2, 2, 512)
+    sd = synth.encoder_state_dict(128, 2, 2, 512, seed=3)
+    mel = olm.log_mel(synth.strain_segments(2, seed=41))
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig(128, 2, 2, 512), precision="bf16").cuda()
+    for p in enc.parameters():
+        p.requires_grad = False
+    x = T.from_numpy(mel).cuda().requires_grad_(True)
+    rng = np.random.default_rng(5)
+    wloss = rng.standard_normal((2, 128))
+    hidden = enc(x).last_hidden_state
+    assert hidden.requires_grad
+    loss = (hidden[:, -1, :] * T.from_numpy(wloss).cuda().float()).sum()
+    loss.backward()
+    g = x.grad.double().cpu().numpy()
+    assert g.shape == mel.shape and np.isfinite(g).all() and np.abs(g).max() > 0
+    sd64 = {k: v.astype(np.float64) for k, v in sd.items()}
+
+    def loss_of(m):
+        out = oenc.encoder_forward(sd64, m, cfg, dtype=np.float64)
+        return float((out[:, -1, :] * wloss).sum())
+
+    eps = 1e-3
+    for trial in range(3):
+        v = rng.standard_normal(mel.shape)
+        if trial == 2:                      # a direction confined to the first / last frames (conv padding edges)
+            v[:, :, 3:-3] = 0.0
+        fd = (loss_of(mel.astype(np.float64) + eps * v) - loss_of(mel.astype(np.float64) - eps * v)) / (2 * eps)
+        an = float((g * v).sum())
+        print(f"d loss / d mel, direction {trial}: analytic(HIP, bf16) {an:.5f}  finite-difference(fp64 oracle) {fd:.5f}")
+        assert abs(an - fd) < 0.06 * abs(fd) + 2e-3, (an, fd)
