@@ -1,0 +1,113 @@
+"""Host-side logic of the search pipeline (gw_whisper_amd/inference.py) against restatements of the reference's
+MLGWSC-1/inference.py and train.py; runs on CPU."""
+import numpy as np
+import torch
+
+from gw_whisper_amd import inference as inf
+
+
+def _reference_get_clusters(triggers, cluster_threshold=0.35):
+    # restated from MLGWSC-1/inference.py:140-166
+    all_clusters = []
+    for trig_list in triggers.values():
+        clusters = []
+        for trig in trig_list:
+            if not clusters or (trig[0] - clusters[-1][-1][0]) > cluster_threshold:
+                clusters.append([trig])
+            else:
+                clusters[-1].append(trig)
+        all_clusters.extend(clusters)
+    times, vals = [], []
+    for cl in all_clusters:
+        vs = np.array([x[1] for x in cl])
+        k = int(np.argmax(vs))
+        times.append(cl[k][0]); vals.append(vs[k])
+    return np.array(times), np.array(vals)
+
+
+def test_get_clusters_matches_reference_algorithm():
+    rng = np.random.default_rng(0)
+    trig = {}
+    for key in ("a", "b", "c"):
+        t = np.sort(rng.uniform(0, 50, 200))
+        trig[key] = [[float(x), float(v)] for x, v in zip(t, rng.uniform(0.2, 1.0, 200))]
+    trig["empty"] = []
+    t0, v0 = _reference_get_clusters(trig)
+    t1, v1, tv = inf.get_clusters(trig)
+    np.testing.assert_array_equal(t0, t1)
+    np.testing.assert_array_equal(v0, v1)
+    assert (tv == 0.2).all() and len(tv) == len(t1)
+
+
+def test_slicer_indexing_matches_reference_iteration():
+    """SegmentSlicer (white=True): window i = samples [i*step, i*step + 2048), time start + i*dt*step + 0.6."""
+    rng = np.random.default_rng(1)
+    strain = rng.standard_normal((2, 2048 * 7 + 123)).astype(np.float32)
+    sl = inf.DeviceSegmentSlicer(strain, start_time=1000.25, device="cpu")
+    assert sl.index_step_size == 204 and abs(sl.time_step_size - 204 / 2048) < 1e-15
+    # reference iteration
+    ref, idx, t = [], 0, 1000.25
+    while idx + 2048 <= strain.shape[1]:
+        ref.append((strain[:, idx:idx + 2048], t + 0.6))
+        idx += 204
+        t += 204 / 2048
+    assert len(sl) == len(ref) == 1 + (strain.shape[1] - 2048) // 204
+    w = sl.windows(0, len(sl)).numpy()
+    ts = sl.times(0, len(sl)).numpy()
+    for i in (0, 1, 17, len(ref) - 1):
+        np.testing.assert_array_equal(w[i], ref[i][0])
+        assert abs(ts[i] - ref[i][1]) < 1e-9
+    part = sl.windows(5, 9).numpy()
+    np.testing.assert_array_equal(part[2], ref[7][0])
+    assert len(inf.DeviceSegmentSlicer(strain[:, :100], device="cpu")) == 0
+
+
+def test_evaluate_slices_thresholds_like_the_reference_loop():
+    rng = np.random.default_rng(2)
+    strain = rng.standard_normal((2, 2048 * 40)).astype(np.float32)
+    sl = inf.DeviceSegmentSlicer(strain, start_time=5.0, device="cpu")
+
+    class Net(torch.nn.Module):   # a deterministic stand-in: score = sigmoid(mean of detector 0 * 40)
+        def forward(self, x):
+            s = torch.sigmoid(x[:, 0].mean(dim=1) * 40)
+            return torch.stack((s, 1 - s), dim=1)
+
+    trig, vals = inf.evaluate_slices(sl, Net(), device="cpu", trigger_threshold=0.6, batch_size=256)
+    n = len(sl)
+    assert sum(len(v) for v in vals) == n and len(vals) == (n + 255) // 256
+    scores = np.concatenate(vals)
+    ref = [[5.0 + i * 204 / 2048 + 0.6, float(scores[i])] for i in range(n) if scores[i] > 0.6]
+    assert len(trig) == len(ref) > 0
+    np.testing.assert_allclose(np.array(trig), np.array(ref), rtol=0, atol=1e-9)
+
+
+def test_shard_windows_is_a_batch_aligned_partition():
+    for n in (1, 255, 256, 257, 100000):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                a, b = inf.shard_windows(n, r, world)
+                assert a % 256 == 0 and a <= b <= n
+                cover += list(range(a, b, 256))
+            assert cover == list(range(0, n, 256))
+
+
+def test_reg_bce_loss_matches_formula():
+    # MLGWSC-1/train.py:358-370
+    rng = np.random.default_rng(3)
+    p = torch.softmax(torch.from_numpy(rng.standard_normal((16, 2))), dim=1)
+    y = torch.from_numpy(np.eye(2)[rng.integers(0, 2, 16)])
+    got = inf.RegBCELoss(dim=2)(p, y).item()
+    x = 1e-6 + (1 - 2e-6) * p.numpy()
+    ref = -(y.numpy() * np.log(x) + (1 - y.numpy()) * np.log(1 - x)).mean()
+    assert abs(got - ref) < 1e-12
+    assert torch.isfinite(inf.RegBCELoss(dim=2)(torch.tensor([[1.0, 0.0]], dtype=torch.float64),
+                                                torch.tensor([[0.0, 1.0]], dtype=torch.float64)))
+
+
+def test_resample_matrix_is_scipy_resample():
+    # Signal_vs_Noise/utils/preprocess.py:44-51: scipy.signal.resample(x, len * 16000 // 2048)
+    from scipy.signal import resample
+    R = inf.resample_matrix(2048, 16000).astype(np.float64)
+    x = np.random.default_rng(4).standard_normal((3, 2048))
+    np.testing.assert_allclose(x @ R.T, resample(x, 16000, axis=1), atol=5e-6)
