@@ -9,6 +9,8 @@
 //     dA = s * ((g * dy) B)^T x              [r, in]
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace gww {
 
 // ---------------------------------------------------------------- LayerNorm backward
@@ -424,12 +426,179 @@ __global__ __launch_bounds__(256) void k_dora_grads(const unsigned short* __rest
   }
 }
 
+// Register-blocked form for d <= 768 (whisper-tiny / base / small): same contract as k_dora_grads.
+//   * A and B^T are staged once per workgroup in LDS (rows padded by 4 floats: conflict-free float4 reads),
+//   * u = x A^T and w = (g dy) B: one 384..768-long dot product per thread, float4 LDS reads of both operands,
+//   * dB / dA: a thread owns whole columns (c, all 8 ranks): per row one read of gs / xs and two broadcast float4
+//     of u / w feed 16 FMAs (the first kernel re-read two LDS words per FMA and re-loaded A / B from L1 per k),
+//   * dm rides in the same column pass.
+template <int D>
+__global__ __launch_bounds__(256) void k_dora_grads_rb(const unsigned short* __restrict__ X, long ldx,
+                                                       const unsigned short* __restrict__ dY,
+                                                       const unsigned short* __restrict__ Y, long ldy,
+                                                       const float* __restrict__ bias_st, float yscale, float scaling,
+                                                       const float* __restrict__ A, const float* __restrict__ Bm,
+                                                       const float* __restrict__ mag, const float* __restrict__ nrm,
+                                                       float* dA, float* dB, float* dm, long M) {
+  constexpr int R = 8, RT = D <= 512 ? 16 : 8, LD = D + 4;   // rows per tile: everything must fit in 160 KB of LDS
+  constexpr int CC = (D + 255) / 256;
+  constexpr int NCH = RT * D / 8 / 256;      // 16-byte chunks of each operand per thread per tile
+  static_assert(D % 8 == 0 && D <= 768 && (RT * D / 8) % 256 == 0, "shape");
+  extern __shared__ __attribute__((aligned(16))) float sm_dg[];
+  float* xs = sm_dg;               // [RT][LD]
+  float* gs = xs + RT * LD;        // [RT][LD]   g * dy_true
+  float* At = gs + RT * LD;        // [R][LD]    A
+  float* Bt = At + R * LD;         // [R][LD]    B^T
+  float* us = Bt + R * LD;         // [RT][R]
+  float* ws = us + RT * R;         // [RT][R]
+  float* gl = ws + RT * R;         // [D]        yscale * mag / nrm
+  unsigned short* ys = reinterpret_cast<unsigned short*>(gl + D);   // [RT][D] bf16 (the dm term)
+  const int tid = threadIdx.x;
+  for (int i = tid; i < R * D; i += 256) {
+    const int j = i / D, k = i - j * D;
+    At[j * LD + k] = A[i];
+    Bt[j * LD + k] = Bm[(long)k * R + j];
+  }
+  for (int i = tid; i < D; i += 256) gl[i] = yscale * (mag[i] / nrm[i]);
+  float accA[CC][R], accB[CC][R], accM[CC], bcol[CC];
+#pragma unroll
+  for (int cc = 0; cc < CC; ++cc) {
+    accM[cc] = 0.f;
+    const int c = tid + 256 * cc;
+    bcol[cc] = c < D ? bias_st[c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < R; ++j) accA[cc][j] = accB[cc][j] = 0.f;
+  }
+  const int which = tid / (RT * R), prr = (tid % (RT * R)) >> 3, pj = tid & 7;   // phase-3 role: (u | w, row, rank)
+
+  // the next tile's X / dY / Y chunks are in flight while the current tile is being reduced
+  u32x4 px[NCH], pd[NCH], py[NCH];
+  auto prefetch = [&](long r0) {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int i = tid + 256 * q;
+      const int rr = i / (D / 8), c8 = (i - rr * (D / 8)) * 8;
+      const long row = r0 + rr;
+      px[q] = pd[q] = py[q] = u32x4{0u, 0u, 0u, 0u};
+      if (row < M) {
+        px[q] = *reinterpret_cast<const u32x4*>(X + row * ldx + c8);
+        pd[q] = *reinterpret_cast<const u32x4*>(dY + row * ldy + c8);
+        py[q] = *reinterpret_cast<const u32x4*>(Y + row * ldy + c8);
+      }
+    }
+  };
+  const long step = (long)gridDim.x * RT;
+  long r0 = (long)blockIdx.x * RT;
+  if (r0 < M) prefetch(r0);
+  for (; r0 < M; r0 += step) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int i = tid + 256 * q;
+      const int rr = i / (D / 8), c8 = (i - rr * (D / 8)) * 8;
+      const u32x4 xv = px[q], dv = pd[q];
+      f32x4 x0, x1, g0, g1;
+      x0[0] = bf2f((unsigned short)(xv[0] & 0xffff)); x0[1] = bf2f((unsigned short)(xv[0] >> 16));
+      x0[2] = bf2f((unsigned short)(xv[1] & 0xffff)); x0[3] = bf2f((unsigned short)(xv[1] >> 16));
+      x1[0] = bf2f((unsigned short)(xv[2] & 0xffff)); x1[1] = bf2f((unsigned short)(xv[2] >> 16));
+      x1[2] = bf2f((unsigned short)(xv[3] & 0xffff)); x1[3] = bf2f((unsigned short)(xv[3] >> 16));
+      g0[0] = bf2f((unsigned short)(dv[0] & 0xffff)); g0[1] = bf2f((unsigned short)(dv[0] >> 16));
+      g0[2] = bf2f((unsigned short)(dv[1] & 0xffff)); g0[3] = bf2f((unsigned short)(dv[1] >> 16));
+      g1[0] = bf2f((unsigned short)(dv[2] & 0xffff)); g1[1] = bf2f((unsigned short)(dv[2] >> 16));
+      g1[2] = bf2f((unsigned short)(dv[3] & 0xffff)); g1[3] = bf2f((unsigned short)(dv[3] >> 16));
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(gl + c8), s1 = *reinterpret_cast<const f32x4*>(gl + c8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        g0[e] *= s0[e];
+        g1[e] *= s1[e];
+      }
+      *reinterpret_cast<f32x4*>(xs + rr * LD + c8) = x0;
+      *reinterpret_cast<f32x4*>(xs + rr * LD + c8 + 4) = x1;
+      *reinterpret_cast<f32x4*>(gs + rr * LD + c8) = g0;
+      *reinterpret_cast<f32x4*>(gs + rr * LD + c8 + 4) = g1;
+      *reinterpret_cast<u32x4*>(ys + rr * D + c8) = py[q];
+    }
+    __syncthreads();
+    if (r0 + step < M) prefetch(r0 + step);
+    if (which < 2) {   // u[rr][j] = x[rr] . A[j]   |   w[rr][j] = gs[rr] . B[:, j]
+      const float* a = (which ? gs : xs) + prr * LD;
+      const float* b = (which ? Bt : At) + pj * LD;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int k = 0; k < D; k += 4) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + k);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b + k);
+        acc[0] = fmaf(av[0], bv[0], acc[0]); acc[1] = fmaf(av[1], bv[1], acc[1]);
+        acc[2] = fmaf(av[2], bv[2], acc[2]); acc[3] = fmaf(av[3], bv[3], acc[3]);
+      }
+      (which ? ws : us)[prr * R + pj] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc) {
+      const int c = tid + 256 * cc;
+      if (c < D) {
+#pragma unroll
+        for (int rr = 0; rr < RT; ++rr) {
+          const float g = gs[rr * LD + c], x = xs[rr * LD + c];
+          const f32x4 u0 = *reinterpret_cast<const f32x4*>(us + rr * R), u1 = *reinterpret_cast<const f32x4*>(us + rr * R + 4);
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws + rr * R), w1 = *reinterpret_cast<const f32x4*>(ws + rr * R + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            accB[cc][j] = fmaf(g, u0[j], accB[cc][j]);
+            accB[cc][4 + j] = fmaf(g, u1[j], accB[cc][4 + j]);
+            accA[cc][j] = fmaf(w0[j], x, accA[cc][j]);
+            accA[cc][4 + j] = fmaf(w1[j], x, accA[cc][4 + j]);
+          }
+          accM[cc] = fmaf(g, bf2f(ys[rr * D + c]) - bcol[cc], accM[cc]);   // g dy_true (y - b); g = 0 on rows past M
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < CC; ++cc) {
+    const int c = tid + 256 * cc;
+    if (c < D) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        atomicAdd(dB + (long)c * R + j, scaling * accB[cc][j]);
+        atomicAdd(dA + (long)j * D + c, scaling * accA[cc][j]);
+      }
+      // accM = sum g_col dy_st (y_st - b_st) with g_col = yscale mag / nrm:  dm = sum dy_st (y_st - b_st) / mag
+      atomicAdd(dm + c, accM[cc] / (gl[c] * mag[c]));
+    }
+  }
+}
+
 int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
                       float yscale, float scaling, const float* A, const float* Bm, const float* mag,
                       const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s) {
   GWW_REQUIRE(r == 8 && (d == 128 || d == 384 || d == 512 || d == 768 || d == 1024 || d == 1280),
               "dora_grads: only r = 8 and d in {128, 384, 512, 768, 1024, 1280} (got d=%d r=%d)", d, r);
   if (M == 0) return GWW_OK;
+  static const bool old_kernel = getenv("GWW_DORA_OLD") != nullptr;   // comparison aid
+  if (d <= 768 && d != 128 && !old_kernel) {
+    static const long nb_env = getenv("GWW_DORA_BLOCKS") ? atol(getenv("GWW_DORA_BLOCKS")) : 0;   // tuning aid
+    const int rt = d <= 512 ? 16 : 8;
+    long nb = cdiv(M, rt);
+    const long nb_max = nb_env > 0 ? nb_env : 256;     // one workgroup per CU: fewer contended atomics at the end
+    if (nb > nb_max) nb = nb_max;
+    const size_t lds = (size_t)((2 * rt + 2 * 8) * (d + 4) + 2 * rt * 8 + d) * 4 + (size_t)rt * d * 2;
+#define GWW_DGR(DD)                                                                                                  \
+  do {                                                                                                               \
+    GWW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dora_grads_rb<DD>),                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
+    hipLaunchKernelGGL((k_dora_grads_rb<DD>), dim3((unsigned)nb), dim3(256), lds, s, (const unsigned short*)X, ldx,  \
+                       (const unsigned short*)dY, (const unsigned short*)Y, ldy, bias_st, yscale, scaling, A, Bm,    \
+                       mag, nrm, dA, dB, dm, M);                                                                     \
+  } while (0)
+    if (d == 384) GWW_DGR(384);
+    else if (d == 512) GWW_DGR(512);
+    else GWW_DGR(768);
+#undef GWW_DGR
+    GWW_LAUNCH_CHECK();
+    return GWW_OK;
+  }
   long blocks = cdiv(M, d <= 512 ? 32 : (d <= 1024 ? 16 : 8));
   if (blocks > 1024) blocks = 1024;
 #define GWW_DG(DD)                                                                                                \
