@@ -53,6 +53,8 @@ SIGNATURES = {
     "gww_encoder_destroy": (None, [C.c_void_p]),
     "gww_encoder_set_weights": (C.c_int, [C.c_void_p, C.POINTER(EncGlobals), C.POINTER(EncLayer),
                                           C.c_int, C.c_void_p]),
+    "gww_encoder_update_weights": (C.c_int, [C.c_void_p, C.POINTER(EncGlobals), C.POINTER(EncLayer), C.c_int,
+                                             C.POINTER(C.c_uint), C.c_void_p]),
     "gww_encoder_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "gww_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),

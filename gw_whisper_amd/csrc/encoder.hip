@@ -244,14 +244,12 @@ extern "C" void gww_encoder_destroy(gww_encoder* e) {
     if (_rc != GWW_OK) return _rc; \
   } while (0)
 
-extern "C" int gww_encoder_set_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_layer* layers,
-                                       int n_layers, void* stream) {
-  GWW_REQUIRE(e && g && layers, "gww_encoder_set_weights: NULL argument");
-  GWW_REQUIRE(n_layers == e->cfg.n_layers, "gww_encoder_set_weights: got %d layers, handle has %d", n_layers,
-              e->cfg.n_layers);
-  GWW_REQUIRE(g->conv1_w && g->conv1_b && g->conv2_w && g->conv2_b && g->pos && g->ln_w && g->ln_b,
-              "gww_encoder_set_weights: NULL global weight");
-  hipStream_t s = (hipStream_t)stream;
+// Weight groups of one layer (bit mask of gww_encoder_update_weights): what has to be re-packed when a
+// parameter of the group changed.
+//   1 = q / k / v projections + their biases + self_attn_layer_norm   (QKV panels, LN-folded panel, transposes)
+//   2 = out_proj          4 = fc1 + final_layer_norm          8 = fc2
+static int pack_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_layer* layers, int n_layers,
+                        const unsigned* dirty, hipStream_t s) {
   const int d = e->cfg.d_model, F = e->cfg.ffn, C = e->cfg.n_mels, T = e->cfg.t_in / 2;
   const float qs = 0.125f;   // head_dim^-0.5 = 64^-0.5, exact power of two (HF:modeling_whisper.py:309)
   auto pack = [&](const float* w, unsigned short* o16, float* o32, int N, int Cin, int taps, int Kpad,
@@ -260,53 +258,91 @@ extern "C" int gww_encoder_set_weights(gww_encoder* e, const gww_enc_globals* g,
     GWW_TRY(launch_pack_weight(w, o32, 0, N, Cin, taps, Kpad, scale, s));
     return GWW_OK;
   };
-  GWW_TRY(pack(g->conv1_w, e->c1w, e->c1w32, d, C, 3, kConv1Kpad, 1.f));
-  GWW_TRY(pack(g->conv2_w, e->c2w, e->c2w32, d, d, 3, 3 * d, 1.f));
-  GWW_TRY(launch_transpose_bf16(e->c1w, e->c1wT, d, kConv1Kpad, s));
-  GWW_TRY(launch_transpose_bf16(e->c2w, e->c2wT, d, 3 * d, s));
-  GWW_TRY(launch_scale_copy(g->conv1_b, e->c1b, d, 1.f, s));
-  GWW_TRY(launch_scale_copy(g->conv2_b, e->c2b, d, 1.f, s));
-  GWW_HIP(hipMemcpyAsync(e->pos, g->pos, (size_t)T * d * 4, hipMemcpyDeviceToDevice, s));
-  GWW_TRY(launch_scale_copy(g->ln_w, e->lnw, d, 1.f, s));
-  GWW_TRY(launch_scale_copy(g->ln_b, e->lnb, d, 1.f, s));
+  if (g) {
+    GWW_REQUIRE(g->conv1_w && g->conv1_b && g->conv2_w && g->conv2_b && g->pos && g->ln_w && g->ln_b,
+                "gww_encoder_set_weights: NULL global weight");
+    GWW_TRY(pack(g->conv1_w, e->c1w, e->c1w32, d, C, 3, kConv1Kpad, 1.f));
+    GWW_TRY(pack(g->conv2_w, e->c2w, e->c2w32, d, d, 3, 3 * d, 1.f));
+    GWW_TRY(launch_transpose_bf16(e->c1w, e->c1wT, d, kConv1Kpad, s));
+    GWW_TRY(launch_transpose_bf16(e->c2w, e->c2wT, d, 3 * d, s));
+    GWW_TRY(launch_scale_copy(g->conv1_b, e->c1b, d, 1.f, s));
+    GWW_TRY(launch_scale_copy(g->conv2_b, e->c2b, d, 1.f, s));
+    GWW_HIP(hipMemcpyAsync(e->pos, g->pos, (size_t)T * d * 4, hipMemcpyDeviceToDevice, s));
+    GWW_TRY(launch_scale_copy(g->ln_w, e->lnw, d, 1.f, s));
+    GWW_TRY(launch_scale_copy(g->ln_b, e->lnb, d, 1.f, s));
+  }
   for (int i = 0; i < n_layers; ++i) {
+    const unsigned m = dirty ? dirty[i] : 15u;
+    if (!m) continue;
     const gww_enc_layer& L = layers[i];
     LayerW& w = e->layers[i];
-    GWW_REQUIRE(L.ln1_w && L.ln1_b && L.q_w && L.q_b && L.k_w && L.v_w && L.v_b && L.o_w && L.o_b && L.ln2_w &&
-                    L.ln2_b && L.fc1_w && L.fc1_b && L.fc2_w && L.fc2_b,
-                "gww_encoder_set_weights: NULL weight in layer %d", i);
     const size_t dd = (size_t)d * d;
-    GWW_TRY(pack(L.q_w, w.wqkv, w.wqkv32, d, d, 1, d, qs));
-    GWW_TRY(pack(L.k_w, w.wqkv + dd, w.wqkv32 + dd, d, d, 1, d, 1.f));
-    GWW_TRY(pack(L.v_w, w.wqkv + 2 * dd, w.wqkv32 + 2 * dd, d, d, 1, d, 1.f));
-    GWW_TRY(pack(L.o_w, w.wo, w.wo32, d, d, 1, d, 1.f));
-    GWW_TRY(pack(L.fc1_w, w.w1, w.w132, F, d, 1, d, 1.f));
-    GWW_TRY(pack(L.fc2_w, w.w2, w.w232, d, F, 1, F, 1.f));
-    GWW_TRY(launch_scale_copy(L.q_b, w.bqkv, d, qs, s));
-    GWW_TRY(launch_scale_copy(nullptr, w.bqkv + d, d, 0.f, s));   // k_proj has no bias
-    GWW_TRY(launch_scale_copy(L.v_b, w.bqkv + 2 * d, d, 1.f, s));
-    GWW_TRY(launch_scale_copy(L.o_b, w.bo, d, 1.f, s));
-    GWW_TRY(launch_scale_copy(L.fc1_b, w.b1, F, 1.f, s));
-    GWW_TRY(launch_scale_copy(L.fc2_b, w.b2, d, 1.f, s));
-    GWW_TRY(launch_scale_copy(L.ln1_w, w.ln1w, d, 1.f, s));
-    GWW_TRY(launch_scale_copy(L.ln1_b, w.ln1b, d, 1.f, s));
-    GWW_TRY(launch_scale_copy(L.ln2_w, w.ln2w, d, 1.f, s));
-    GWW_TRY(launch_scale_copy(L.ln2_b, w.ln2b, d, 1.f, s));
-    // gain-folded panels + correction vectors for the algebraic LayerNorm of the A-stationary GEMMs
-    GWW_TRY(launch_ln_fold(L.q_w, L.ln1_w, L.ln1_b, L.q_b, qs, d, d, w.wqkv_ln, w.uqkv, w.cbqkv, s));
-    GWW_TRY(launch_ln_fold(L.k_w, L.ln1_w, L.ln1_b, nullptr, 1.f, d, d, w.wqkv_ln + dd, w.uqkv + d, w.cbqkv + d, s));
-    GWW_TRY(launch_ln_fold(L.v_w, L.ln1_w, L.ln1_b, L.v_b, 1.f, d, d, w.wqkv_ln + 2 * dd, w.uqkv + 2 * d,
-                           w.cbqkv + 2 * d, s));
-    GWW_TRY(launch_ln_fold(L.fc1_w, L.ln2_w, L.ln2_b, L.fc1_b, 1.f, F, d, w.w1_ln, w.u1, w.cb1, s));
-    if (d == 384 && F % 128 == 0 && F <= 1536) GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, w.wmlp, d, F, s));
-    // transposed panels for the backward dX GEMMs:  [N][K] -> [K][N]
-    GWW_TRY(launch_transpose_bf16(w.wqkv, w.wqkvT, 3 * d, d, s));
-    GWW_TRY(launch_transpose_bf16(w.wo, w.woT, d, d, s));
-    GWW_TRY(launch_transpose_bf16(w.w1, w.w1T, F, d, s));
-    GWW_TRY(launch_transpose_bf16(w.w2, w.w2T, d, F, s));
+    if (m & 1u) {
+      GWW_REQUIRE(L.ln1_w && L.ln1_b && L.q_w && L.q_b && L.k_w && L.v_w && L.v_b,
+                  "gww_encoder_set_weights: NULL attention weight in layer %d", i);
+      GWW_TRY(pack(L.q_w, w.wqkv, w.wqkv32, d, d, 1, d, qs));
+      GWW_TRY(pack(L.k_w, w.wqkv + dd, w.wqkv32 + dd, d, d, 1, d, 1.f));
+      GWW_TRY(pack(L.v_w, w.wqkv + 2 * dd, w.wqkv32 + 2 * dd, d, d, 1, d, 1.f));
+      GWW_TRY(launch_scale_copy(L.q_b, w.bqkv, d, qs, s));
+      GWW_TRY(launch_scale_copy(nullptr, w.bqkv + d, d, 0.f, s));   // k_proj has no bias
+      GWW_TRY(launch_scale_copy(L.v_b, w.bqkv + 2 * d, d, 1.f, s));
+      GWW_TRY(launch_scale_copy(L.ln1_w, w.ln1w, d, 1.f, s));
+      GWW_TRY(launch_scale_copy(L.ln1_b, w.ln1b, d, 1.f, s));
+      // gain-folded panel + correction vectors for the algebraic LayerNorm of the A-stationary GEMM
+      GWW_TRY(launch_ln_fold(L.q_w, L.ln1_w, L.ln1_b, L.q_b, qs, d, d, w.wqkv_ln, w.uqkv, w.cbqkv, s));
+      GWW_TRY(launch_ln_fold(L.k_w, L.ln1_w, L.ln1_b, nullptr, 1.f, d, d, w.wqkv_ln + dd, w.uqkv + d, w.cbqkv + d, s));
+      GWW_TRY(launch_ln_fold(L.v_w, L.ln1_w, L.ln1_b, L.v_b, 1.f, d, d, w.wqkv_ln + 2 * dd, w.uqkv + 2 * d,
+                             w.cbqkv + 2 * d, s));
+      GWW_TRY(launch_transpose_bf16(w.wqkv, w.wqkvT, 3 * d, d, s));   // [N][K] -> [K][N] for the backward dX GEMM
+    }
+    if (m & 2u) {
+      GWW_REQUIRE(L.o_w && L.o_b, "gww_encoder_set_weights: NULL out_proj weight in layer %d", i);
+      GWW_TRY(pack(L.o_w, w.wo, w.wo32, d, d, 1, d, 1.f));
+      GWW_TRY(launch_scale_copy(L.o_b, w.bo, d, 1.f, s));
+      GWW_TRY(launch_transpose_bf16(w.wo, w.woT, d, d, s));
+    }
+    if (m & 4u) {
+      GWW_REQUIRE(L.ln2_w && L.ln2_b && L.fc1_w && L.fc1_b, "gww_encoder_set_weights: NULL fc1 weight in layer %d", i);
+      GWW_TRY(pack(L.fc1_w, w.w1, w.w132, F, d, 1, d, 1.f));
+      GWW_TRY(launch_scale_copy(L.fc1_b, w.b1, F, 1.f, s));
+      GWW_TRY(launch_scale_copy(L.ln2_w, w.ln2w, d, 1.f, s));
+      GWW_TRY(launch_scale_copy(L.ln2_b, w.ln2b, d, 1.f, s));
+      GWW_TRY(launch_ln_fold(L.fc1_w, L.ln2_w, L.ln2_b, L.fc1_b, 1.f, F, d, w.w1_ln, w.u1, w.cb1, s));
+      GWW_TRY(launch_transpose_bf16(w.w1, w.w1T, F, d, s));
+    }
+    if (m & 8u) {
+      GWW_REQUIRE(L.fc2_w && L.fc2_b, "gww_encoder_set_weights: NULL fc2 weight in layer %d", i);
+      GWW_TRY(pack(L.fc2_w, w.w2, w.w232, d, F, 1, F, 1.f));
+      GWW_TRY(launch_scale_copy(L.fc2_b, w.b2, d, 1.f, s));
+      GWW_TRY(launch_transpose_bf16(w.w2, w.w2T, d, F, s));
+    }
+    // the fused-MLP weight stream holds the folded fc1 panel and fc2
+    if ((m & 12u) && d == 384 && F % 128 == 0 && F <= 1536) GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, w.wmlp, d, F, s));
   }
+  return GWW_OK;
+}
+
+extern "C" int gww_encoder_set_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_layer* layers,
+                                       int n_layers, void* stream) {
+  GWW_REQUIRE(e && g && layers, "gww_encoder_set_weights: NULL argument");
+  GWW_REQUIRE(n_layers == e->cfg.n_layers, "gww_encoder_set_weights: got %d layers, handle has %d", n_layers,
+              e->cfg.n_layers);
+  GWW_TRY(pack_weights(e, g, layers, n_layers, nullptr, (hipStream_t)stream));
   e->ready = true;
   return GWW_OK;
+}
+
+// Re-pack only what changed since the last (full) gww_encoder_set_weights: `globals` may be NULL (stem, positions,
+// final LayerNorm unchanged); layer_dirty[i] is the group mask above (0 = layer untouched; pointers of clean
+// groups are not read).  A DoRA step touches group 1 (and 2) only: 15 small kernels per layer instead of 40.
+extern "C" int gww_encoder_update_weights(gww_encoder* e, const gww_enc_globals* globals_or_null,
+                                          const gww_enc_layer* layers, int n_layers, const unsigned* layer_dirty,
+                                          void* stream) {
+  GWW_REQUIRE(e && layers && layer_dirty, "gww_encoder_update_weights: NULL argument");
+  GWW_REQUIRE(n_layers == e->cfg.n_layers, "gww_encoder_update_weights: got %d layers, handle has %d", n_layers,
+              e->cfg.n_layers);
+  if (!e->ready) return fail(GWW_ERR_STATE, "gww_encoder_update_weights: call gww_encoder_set_weights first");
+  return pack_weights(e, globals_or_null, layers, n_layers, layer_dirty, (hipStream_t)stream);
 }
 
 namespace {
@@ -625,6 +661,7 @@ extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int b
                            Tin + 2, s, 0));
   GWW_TRY(launch_gemm_bf16(c1, 2L * d, e->c2w, e->c2b, nullptr, e->pos, x_in(0), (long)B * (T + 1), d, 3 * d, EPI_CONV2,
                            T + 1, s, 1));
+  const bool fast = (d == 384 || d == 512) && F % 128 == 0;   // A-stationary kernel for the K = d GEMMs without a residual
   for (int l = 0; l < L; ++l) {
     const LayerW& W = e->layers[l];
     char* lb = sv + (size_t)l * sl.layer_stride;
@@ -635,11 +672,13 @@ extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int b
     float* x_mid = (float*)(lb + sl.x_mid);
     void* z = lb + sl.z;
     GWW_TRY(launch_layernorm(x_in(l), W.ln1w, W.ln1b, h1, 1, M, d, s));
-    GWW_TRY(launch_gemm_bf16(h1, d, W.wqkv, W.bqkv, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0, s, 1));
+    if (fast) GWW_TRY(launch_gemm_astat(h1, d, nullptr, nullptr, nullptr, nullptr, W.wqkv, W.bqkv, qkv, M, 3 * d, d, EPI_BIAS, 0, s));
+    else GWW_TRY(launch_gemm_bf16(h1, d, W.wqkv, W.bqkv, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0, s, 1));
     GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s, lse));
     GWW_TRY(launch_gemm_bf16(ctx, d, W.wo, W.bo, x_in(l), nullptr, x_mid, M, d, d, EPI_RESID, 0, s, 1));
     GWW_TRY(launch_layernorm(x_mid, W.ln2w, W.ln2b, h2, 1, M, d, s));
-    GWW_TRY(launch_gemm_bf16(h2, d, W.w1, W.b1, nullptr, nullptr, z, M, F, d, EPI_BIAS, 0, s, 1));
+    if (fast) GWW_TRY(launch_gemm_astat(h2, d, nullptr, nullptr, nullptr, nullptr, W.w1, W.b1, z, M, F, d, EPI_BIAS, 0, s));
+    else GWW_TRY(launch_gemm_bf16(h2, d, W.w1, W.b1, nullptr, nullptr, z, M, F, d, EPI_BIAS, 0, s, 1));
     GWW_TRY(launch_gelu_bf16(z, nullptr, f1, ((M * F + 7) / 8) * 8, s));
     GWW_TRY(launch_gemm_bf16(f1, F, W.w2, W.b2, x_mid, nullptr, x_in(l + 1), M, d, F, EPI_RESID, 0, s, 1));
   }
@@ -682,6 +721,16 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
     GWW_REQUIRE(t.layer >= 0 && t.layer < L && t.proj >= 0 && t.proj <= 3, "gww_encoder_train_backward: bad target %d", i);
     GWW_REQUIRE(t.A && t.B && t.mag && t.nrm && t.dA && t.dB && t.dm, "gww_encoder_train_backward: NULL pointer in target %d", i);
   }
+  // dX GEMMs: A-stationary kernel for the K <= 512 contractions, full-N kernel for the long-K, N = d ones
+  // (d = 384 / 512); generic tiles otherwise.  All buffers are padded to whole 256-row panels.
+  const bool fast = (d == 384 || d == 512) && F % 128 == 0;
+  auto gemm_dx = [&](const void* A, long lda, const void* Wt, void* Cout, int N, int K) -> int {
+    if (fast && lda == K && (K == 384 || K == 512) && N % 128 == 0)
+      return launch_gemm_astat(A, lda, nullptr, nullptr, nullptr, nullptr, Wt, nullptr, Cout, M, N, K, EPI_BIAS, 0, s);
+    if (fast && N == d && K % 64 == 0 && K > 512)
+      return launch_gemm_fulln(A, lda, Wt, nullptr, nullptr, Cout, M, N, K, EPI_BIAS, 0, s);
+    return launch_gemm_bf16(A, lda, Wt, nullptr, nullptr, nullptr, Cout, M, N, K, EPI_BIAS, 0, s, 1);
+  };
   // final LayerNorm backward -> dx (grad w.r.t. x_in[L])
   GWW_TRY(launch_ln_bwd(x_in(L), e->lnw, d_last_hidden, 1, dx, 0, dxb, M, d, s));
   for (int l = L - 1; l >= 0; --l) {
@@ -694,9 +743,9 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
     const float* x_mid = (const float*)(lb + sl.x_mid);
     const void* z = lb + sl.z;
     // fc2 / GELU / fc1 / LN2   (x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))))
-    GWW_TRY(launch_gemm_bf16(dxb, d, W.w2T, nullptr, nullptr, nullptr, dbig, M, F, d, EPI_BIAS, 0, s, 1));
+    GWW_TRY(gemm_dx(dxb, d, W.w2T, dbig, F, d));
     GWW_TRY(launch_gelu_bf16(z, dbig, dbig, ((M * F + 7) / 8) * 8, s));
-    GWW_TRY(launch_gemm_bf16(dbig, F, W.w1T, nullptr, nullptr, nullptr, dh, M, d, F, EPI_BIAS, 0, s, 1));
+    GWW_TRY(gemm_dx(dbig, F, W.w1T, dh, d, F));
     GWW_TRY(launch_ln_bwd(x_mid, W.ln2w, dh, 0, dx, 1, dxb, M, d, s));
     // out_proj / attention / QKV / LN1   (x_mid = x_in + out_proj(attn(qkv(LN1(x_in)))))
     {   // out_proj DoRA targets: x = ctx, dy = d(x_mid) (= dxb), y = x_mid - x_in (rebuilt into dh, free here)
@@ -712,7 +761,7 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
                                   M, d, t.r, s));
       }
     }
-    GWW_TRY(launch_gemm_bf16(dxb, d, W.woT, nullptr, nullptr, nullptr, dctx, M, d, d, EPI_BIAS, 0, s, 1));
+    GWW_TRY(gemm_dx(dxb, d, W.woT, dctx, d, d));
     GWW_TRY(launch_attention_bwd_bf16(qkv, ctx, dctx, lse, Dv, dqkv, B, T, H, s));
     for (int i = 0; i < n_targets; ++i) {
       const gww_dora_target& t = targets[i];
@@ -722,7 +771,7 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
                                 W.bqkv + off, t.proj == 0 ? 0.125f : 1.0f, t.scaling, t.A, t.B, t.mag, t.nrm, t.dA,
                                 t.dB, t.dm, M, d, t.r, s));
     }
-    GWW_TRY(launch_gemm_bf16(dqkv, 3L * d, W.wqkvT, nullptr, nullptr, nullptr, dh, M, d, 3 * d, EPI_BIAS, 0, s, 1));
+    GWW_TRY(gemm_dx(dqkv, 3L * d, W.wqkvT, dh, d, 3 * d));
     GWW_TRY(launch_ln_bwd(x_in(l), W.ln1w, dh, 0, dx, 1, dxb, M, d, s));
   }
   if (d_x0) GWW_HIP(hipMemcpyAsync(d_x0, dx, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));

@@ -145,15 +145,34 @@ class WhisperEncoder(nn.Module):
             self._handle = h
         return self._handle
 
-    def _weights_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+    @staticmethod
+    def _mod_key(*mods):
+        """(data_ptr, version) of every parameter under the given modules (DoRA wrappers included)."""
+        return tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+
+    def _group_keys(self):
+        """Change keys per weight group: globals, and per layer the four groups of gww_encoder_update_weights
+        (bit 0 q/k/v + LN1, bit 1 out_proj, bit 2 fc1 + LN2, bit 3 fc2)."""
+        g = self._mod_key(self.conv1, self.conv2, self.embed_positions, self.layer_norm)
+        layers = []
+        for L in self.layers:
+            a = L.self_attn
+            layers.append((self._mod_key(a.q_proj, a.k_proj, a.v_proj, L.self_attn_layer_norm),
+                           self._mod_key(a.out_proj), self._mod_key(L.fc1, L.final_layer_norm), self._mod_key(L.fc2)))
+        return g, layers
 
     def _sync_weights(self):
-        """Re-pack into the library's bf16/fp32 panels when any parameter changed
-        (optimizer step, load_state_dict, DoRA update)."""
-        key = self._weights_key()
-        if key == self._packed_key:
+        """Re-pack into the library's bf16/fp32 panels what changed since the last call (optimizer step,
+        load_state_dict, DoRA update): everything the first time, afterwards only the dirty weight groups
+        (a DoRA step touches the attention projections: the frozen fc1 / fc2 / stem panels are packed once)."""
+        gkey, lkeys = self._group_keys()
+        old = self._packed_key
+        if old is not None and old == (gkey, lkeys):
             return
+        full = old is None
+        g_dirty = full or old[0] != gkey
+        masks = [15 if full else sum((1 << b) for b in range(4) if old[1][i][b] != lkeys[i][b])
+                 for i in range(len(self.layers))]
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         keep = []   # keep temporaries alive until the async packing kernels are enqueued
 
@@ -162,25 +181,34 @@ class WhisperEncoder(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        g = _lib.EncGlobals(ptr(self.conv1.weight), ptr(self.conv1.bias), ptr(self.conv2.weight),
-                            ptr(self.conv2.bias), ptr(self.embed_positions.weight), ptr(self.layer_norm.weight),
-                            ptr(self.layer_norm.bias))
+        g = None
+        if g_dirty:
+            g = _lib.EncGlobals(ptr(self.conv1.weight), ptr(self.conv1.bias), ptr(self.conv2.weight),
+                                ptr(self.conv2.bias), ptr(self.embed_positions.weight), ptr(self.layer_norm.weight),
+                                ptr(self.layer_norm.bias))
         n = len(self.layers)
         arr = (_lib.EncLayer * n)()
         for i, L in enumerate(self.layers):
-            a = L.self_attn
+            a, m = L.self_attn, masks[i]
+            z = lambda cond, fn: fn() if cond else None       # clean groups: pointers are not read
             arr[i] = _lib.EncLayer(
-                ptr(L.self_attn_layer_norm.weight), ptr(L.self_attn_layer_norm.bias),
-                ptr(_effective_weight(a.q_proj)), ptr(_bias(a.q_proj)),
-                ptr(_effective_weight(a.k_proj)),
-                ptr(_effective_weight(a.v_proj)), ptr(_bias(a.v_proj)),
-                ptr(_effective_weight(a.out_proj)), ptr(_bias(a.out_proj)),
-                ptr(L.final_layer_norm.weight), ptr(L.final_layer_norm.bias),
-                ptr(_effective_weight(L.fc1)), ptr(_bias(L.fc1)),
-                ptr(_effective_weight(L.fc2)), ptr(_bias(L.fc2)))
-        check(lib().gww_encoder_set_weights(self._ensure_handle(), C.byref(g), arr, n,
-                                            torch.cuda.current_stream().cuda_stream), "gww_encoder_set_weights")
-        self._packed_key = key
+                z(m & 1, lambda: ptr(L.self_attn_layer_norm.weight)), z(m & 1, lambda: ptr(L.self_attn_layer_norm.bias)),
+                z(m & 1, lambda: ptr(_effective_weight(a.q_proj))), z(m & 1, lambda: ptr(_bias(a.q_proj))),
+                z(m & 1, lambda: ptr(_effective_weight(a.k_proj))),
+                z(m & 1, lambda: ptr(_effective_weight(a.v_proj))), z(m & 1, lambda: ptr(_bias(a.v_proj))),
+                z(m & 2, lambda: ptr(_effective_weight(a.out_proj))), z(m & 2, lambda: ptr(_bias(a.out_proj))),
+                z(m & 4, lambda: ptr(L.final_layer_norm.weight)), z(m & 4, lambda: ptr(L.final_layer_norm.bias)),
+                z(m & 4, lambda: ptr(_effective_weight(L.fc1))), z(m & 4, lambda: ptr(_bias(L.fc1))),
+                z(m & 8, lambda: ptr(_effective_weight(L.fc2))), z(m & 8, lambda: ptr(_bias(L.fc2))))
+        stream = torch.cuda.current_stream().cuda_stream
+        if full:
+            check(lib().gww_encoder_set_weights(self._ensure_handle(), C.byref(g), arr, n, stream),
+                  "gww_encoder_set_weights")
+        else:
+            dirty = (C.c_uint * n)(*masks)
+            check(lib().gww_encoder_update_weights(self._ensure_handle(), C.byref(g) if g is not None else None, arr, n,
+                                                   dirty, stream), "gww_encoder_update_weights")
+        self._packed_key = (gkey, lkeys)
 
     def _workspace(self, batch: int, prec: int, device) -> torch.Tensor:
         need = lib().gww_encoder_workspace_bytes(self._ensure_handle(), batch, prec)

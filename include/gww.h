@@ -105,6 +105,13 @@ void gww_encoder_destroy(gww_encoder* enc);
  * DoRA merge.  Asynchronous on `stream`. */
 int gww_encoder_set_weights(gww_encoder* enc, const gww_enc_globals* g,
                             const gww_enc_layer* layers, int n_layers, void* stream);
+/* Re-pack only the weight groups that changed since the last full gww_encoder_set_weights (an optimizer step on
+ * the DoRA parameters touches the q / k / v / out projections only).  globals_or_null: stem / positions / final
+ * LayerNorm, NULL if unchanged.  layer_dirty[i]: bit 0 = q, k, v projections + self_attn_layer_norm, bit 1 =
+ * out_proj, bit 2 = fc1 + final_layer_norm, bit 3 = fc2; pointers of clean groups are not read. */
+int gww_encoder_update_weights(gww_encoder* enc, const gww_enc_globals* globals_or_null,
+                               const gww_enc_layer* layers, int n_layers, const unsigned* layer_dirty,
+                               void* stream);
 /* bytes of caller-owned scratch gww_encoder_forward needs for `batch` segments */
 size_t gww_encoder_workspace_bytes(const gww_encoder* enc, int batch, int precision);
 /* mel [batch,80,3000] fp32 (== input_features).  Either output may be NULL:
