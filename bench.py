@@ -365,7 +365,7 @@ def main():
                                     "launches_per_step": dom["launches_per_step"]}
         if args.isolated and args.precision == "bf16":
             line["kernels_isolated"] = kernel_breakdown(args.encoder, B, dev)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only (rank 0's host cores)
             line["cpu_baseline"] = cpu_baseline(args.encoder)
         print(json.dumps(line), flush=True)
     if world > 1:

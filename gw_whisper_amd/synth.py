@@ -18,6 +18,7 @@ ENCODER_SIZES = {
     "tiny": (384, 4, 6, 1536),
     "base": (512, 6, 8, 2048),
     "small": (768, 12, 12, 3072),
+    "micro": (128, 2, 2, 512),      # not a Whisper size: the reduced geometry the parity tests use
 }
 
 

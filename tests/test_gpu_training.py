@@ -265,3 +265,25 @@ def test_input_gradient_through_the_conv_stem(T, gww):
         an = float((g * v).sum())
         print(f"d loss / d mel, direction {trial}: analytic(HIP, bf16) {an:.5f}  finite-difference(fp64 oracle) {fd:.5f}")
         assert abs(an - fd) < 0.06 * abs(fd) + 2e-3, (an, fd)
+
+
+def test_run_train_harness_end_to_end(T, gww, tmp_path):
+    """harness/run_train.py (counterpart of Signal_vs_Noise/run_train.py): two epochs on synthetic chirps with the
+    reduced encoder: the loss goes down, the artefacts have the reference's names and load back."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path)
+    cmd = [sys.executable, os.path.join(root, "harness", "run_train.py"), "--synthetic", "96", "--encoder", "micro",
+           "--batch-size", "16", "--num-epochs", "3", "--learning-rate", "1e-3", "--models-path", out + "/models",
+           "--log-dir", out + "/logs"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    recs = [json.loads(l) for l in open(out + "/logs/train_log.jsonl")]
+    assert len(recs) == 3 and all(np.isfinite(x["train_loss"]) and np.isfinite(x["val_loss"]) for x in recs)
+    assert recs[-1]["train_loss"] < recs[0]["train_loss"]
+    for name in ("lora_weights_8_32", "best_lora_weights_8_32"):
+        assert os.path.exists(f"{out}/models/{name}/adapter_config.json")
+        assert os.path.exists(f"{out}/models/{name}/adapter_model.safetensors")
+    assert os.path.exists(out + "/models/dense_layers_8_32.pth") and os.path.exists(out + "/models/best_dense_layers_8_32.pth")
+    cfg = json.load(open(out + "/models/lora_weights_8_32/adapter_config.json"))
+    assert cfg["use_dora"] is True and cfg["r"] == 8 and cfg["lora_alpha"] == 32 and len(cfg["target_modules"]) == 6
