@@ -16,7 +16,7 @@ __all__ = ["GwwError", "LIB_PATH", "lib"]
 def __getattr__(name):
     # torch-dependent pieces are imported lazily so `import gw_whisper_amd` stays cheap
     import importlib
-    if name in ("ops", "encoder", "synth", "feature_extraction", "peft", "models", "dist", "training", "inference"):
+    if name in ("ops", "encoder", "synth", "feature_extraction", "peft", "models", "dist", "training", "inference", "qscan"):
         return importlib.import_module(f"{__name__}.{name}")
     if name in ("WhisperEncoder", "WhisperConfig"):
         return getattr(importlib.import_module(f"{__name__}.encoder"), name)

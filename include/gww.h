@@ -231,6 +231,22 @@ int gww_mlp_fused_bf16(const float* x, const void* delta, float* x_out, const fl
 /* Pre-tile the weights of gww_mlp_fused_bf16: w1_folded bf16 [F,384] (gww_ln_fold_weights), w2 bf16 [384,F]
  * -> out bf16, 2*384*F elements, as the sequence of swizzled 16-KiB LDS images the kernel streams. */
 int gww_mlp_pack_bf16(const void* w1_folded, const void* w2, void* out, int d, int F, void* stream);
+/* Q-transform front end #2 (ml4gw QScan as used by MLGWSC-1/train.py:117-122,135-154; PARITY UNPINNED: ml4gw is not
+ * vendored, pinned or installed -- the kernels follow oracle/qscan.py).  The host builds the static tiling once
+ * (gw_whisper_amd/qscan.py): rows = int [n_rows][6] (plane, ntiles, windowsize, first data index, energy offset,
+ * window offset) plane by plane in frequency order; order = row indices sorted by ntiles; class_ranges_host = [first,
+ * last) positions in `order` for ntiles 128, 256, 512, 1024, 2048; window = the bisquare windows back to back.
+ * fseries: fp32 [B, ld] (re, im) forward-normalised one-sided spectrum with the positive frequencies doubled (one
+ * gww_gemm_f32 against the real-DFT matrix).  energy: fp32 [B, e_total] median-normalised tile energies; plane_max:
+ * uint [n_planes] (float bits of each plane's largest energy over the whole batch; zeroed by the call). */
+int gww_qscan_energy_f32(const float* fseries, int ld, int B, const int* rows, const int* order,
+                         const int* class_ranges_host, const float* window, float* energy, long e_total,
+                         unsigned int* plane_max, int n_planes, void* stream);
+/* Select the plane with the largest energy over the batch (on the device) and resample it to out fp32 [B, F, T]
+ * with PyTorch's bicubic rules (time per row, then frequency).  plane_rows: device int [n_planes][2] = first row,
+ * row count.  chosen (optional): device int receiving the selected plane. */
+int gww_qscan_interp_f32(const float* energy, long e_total, const int* rows, const int* plane_rows, int n_planes,
+                         const unsigned int* plane_max, int B, int F, int T, float* out, int* chosen, void* stream);
 int gww_gemm_f32(const float* A, const float* W, const float* bias, const float* resid, float* C,
                  long M, int N, int K, int epilogue, void* stream);
 /* softmax(q k^T) v per head, q pre-scaled; qkv [B,T,3*d] (q|k|v), ctx [B,T,d]; head_dim 64 */

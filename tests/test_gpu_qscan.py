@@ -1,0 +1,87 @@
+"""Q-transform front end #2 on the GPU against the CPU restatement oracle/qscan.py.  PARITY UNPINNED with respect
+to ml4gw (absent, unpinned upstream): these tests pin the HIP kernels to the restatement only."""
+import numpy as np
+import pytest
+
+from oracle import qscan as oq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _signals(n, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, 2048))
+    t = np.arange(2048) / 2048.0
+    for i in range(0, n, 2):      # chirps of different loudness: different Q planes win
+        x[i] += (3.0 + i) * np.sin(2 * np.pi * (60 + 300 * t) * t) * np.exp(-((t - 0.55) / 0.08) ** 2)
+    return x
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (5, 1), (9, 2)])
+def test_qscan_matches_restatement(T, gww, n, seed):
+    from gw_whisper_amd.qscan import QScan
+    x = _signals(n, seed)
+    ref, best = oq.qscan(x, return_plane=True)
+    qs = QScan(duration=1.0, sample_rate=2048, spectrogram_shape=[128, 128], qrange=[4, 128])
+    out = qs(T.from_numpy(x.astype(np.float32)).cuda())
+    assert out.shape == (n, 128, 128)
+    assert int(qs.last_plane.item()) == best          # plane with the largest energy over the WHOLE batch
+    got = out.cpu().numpy()
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    print(f"qscan n={n}: plane {best}, max |err| {err:.3e} (max value {scale:.1f})")
+    assert err < 2e-3 * max(scale, 1.0)
+
+
+def test_qscan_plane_choice_is_batch_global(T, gww):
+    """The same segment gives a different spectrogram when a loud neighbour moves the batch-wide argmax to another
+    plane (SURVEY.md section 8e caveat) -- the kernels reproduce that, it is not a per-sample choice."""
+    from gw_whisper_amd.qscan import QScan
+    qs = QScan(duration=1.0, sample_rate=2048, spectrogram_shape=[128, 128], qrange=[4, 128])
+    rng = np.random.default_rng(7)
+    quiet = rng.standard_normal((1, 2048))
+    t = np.arange(2048) / 2048.0
+    loud = 40.0 * np.sin(2 * np.pi * 700 * t)[None] * np.exp(-((t - 0.5) / 0.3) ** 2) + rng.standard_normal((1, 2048))
+    alone = qs(T.from_numpy(quiet.astype(np.float32)).cuda())
+    p_alone = int(qs.last_plane.item())
+    both = qs(T.from_numpy(np.concatenate([quiet, loud]).astype(np.float32)).cuda())
+    p_both = int(qs.last_plane.item())
+    ref_alone, b0 = oq.qscan(quiet, return_plane=True)
+    ref_both, b1 = oq.qscan(np.concatenate([quiet, loud]), return_plane=True)
+    assert (p_alone, p_both) == (b0, b1)
+    np.testing.assert_allclose(alone.cpu().numpy(), ref_alone, atol=2e-3 * np.abs(ref_alone).max())
+    np.testing.assert_allclose(both.cpu().numpy(), ref_both, atol=2e-3 * np.abs(ref_both).max())
+
+
+def test_q_adapter_feeds_the_encoder_and_trains_through_it(T, gww):
+    """QTransformAdapter (MLGWSC-1/train.py:78-154) -> [B, D, 80, 3000] -> frozen encoder; the adapter's CNN and
+    FiLM parameters receive gradients through the encoder's input gradient (train.py:494-504)."""
+    from gw_whisper_amd import synth
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    from gw_whisper_amd.inference import GWWhisperClassifier
+    from gw_whisper_amd.qscan import QTransformAdapter
+    T.manual_seed(0)
+    sd = synth.encoder_state_dict(128, 2, 2, 512, seed=3)
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig(128, 2, 2, 512), precision="bf16").cuda()
+    for p in enc.parameters():
+        p.requires_grad = False
+    model = GWWhisperClassifier(enc, n_detectors=2, num_classes=2, adapter=QTransformAdapter(n_detectors=2)).cuda()
+    names = {n for n, _ in model.adapter.named_parameters()}
+    assert {"scale", "bias", "film_gamma", "film_beta", "freq_adapter.0.weight", "freq_adapter.8.weight"} <= names
+    x = T.from_numpy(_signals(3, 4).astype(np.float32)).cuda()[:, None, :].repeat(1, 2, 1)
+    feats = model.adapter(x)
+    assert feats.shape == (3, 2, 80, 3000) and T.isfinite(feats).all()
+    probs = model(x)
+    assert probs.shape == (3, 2) and T.allclose(probs.sum(1), T.ones(3, device="cuda"), atol=1e-5)
+    loss = -T.log(probs[:, 0] + 1e-6).mean()
+    loss.backward()
+    for n, p in model.adapter.named_parameters():
+        assert p.grad is not None and T.isfinite(p.grad).all(), n
+    assert model.adapter.film_gamma.grad.abs().max() > 0 and model.adapter.freq_adapter[0].weight.grad.abs().max() > 0
