@@ -239,6 +239,12 @@ def main():
     wave = torch.from_numpy(synth.strain_segments(B, seed=1000 + rank)).to(dev)
     mel = ops.logmel(wave)
     fe_ms = time_kernel(lambda: ops.logmel(wave), iters=5, warm=1)
+    # front end #2 (BASELINE configs 4 / 5): Q-scan of B two-detector 1 s windows at 2048 Hz -> [2 B, 128, 128]
+    from gw_whisper_amd.qscan import QScan
+    qs = QScan(duration=1.0, sample_rate=2048, spectrogram_shape=[128, 128], qrange=[4, 128])
+    strain2k = torch.from_numpy(synth.strain_segments(2 * B, seed=2000 + rank, n_samples=2048)).to(dev)
+    q_ms = time_kernel(lambda: qs(strain2k), iters=5, warm=1)
+    del strain2k
 
     def step():
         return enc.forward_raw(mel, want_hidden=True, want_last=True)
@@ -307,6 +313,9 @@ def main():
                          "segments_per_s": B / fe_ms * 1e3,
                          "algorithmic_gbs": B * (64000 + 960000) / fe_ms / 1e6,
                          "frac_of_hbm_peak": B * (64000 + 960000) / fe_ms / 1e6 / HBM_PEAK_GBS},
+            "frontend_qscan": {"kernel": "rDFT GEMM + k_qscan_tiles + k_qscan_interp (parity unpinned, DESIGN.md section 2)",
+                               "ms_per_batch": q_ms, "windows_per_s": 2 * B / q_ms * 1e3,
+                               "config": f"{2 * B} x 2048 samples, qrange [4, 128], 148 tiles rows, 128 x 128 output"},
             "dora_step_ms": train["ms"] if train else None,
             "dora_step": train,
         }
