@@ -29,9 +29,11 @@ int launch_sub_f32_bf16(const float* a, const float* b, void* out, long n, hipSt
 int launch_stem_dz2(const void* dxb, const void* z2, void* out, int B, int T, int d, hipStream_t s);
 int launch_stem_dz1(const void* col, const void* z1, void* out, int B, int T, int Tin, int d, hipStream_t s);
 int launch_stem_dmel(const void* col1, float* dmel, int B, int Tin, int C, int Kp, hipStream_t s);
-int launch_mlp_pack(const void* w1_folded, const void* w2, void* out, int d, int F, hipStream_t s);
+int launch_mlp_pack(const void* w1_folded, const void* w2, const void* wqkv_folded, void* out, int d, int F, int NQ,
+                    hipStream_t s);
 int launch_mlp_fused(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
-                     const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s);
+                     const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s,
+                     const float* q_u = nullptr, const float* q_cb = nullptr, void* q_out = nullptr, int NQ = 0);
 int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
                       float yscale, float scaling, const float* A, const float* Bm, const float* mag,
                       const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s);
@@ -131,7 +133,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
     lo[i].ln2b = take(d * 4);
     lo[i].wqkv_ln = take((size_t)3 * d * d * 2);
     lo[i].w1_ln = take((size_t)F * d * 2);
-    lo[i].wmlp = take((size_t)2 * F * d * 2);
+    lo[i].wmlp = take(((size_t)2 * F * d + (size_t)3 * d * d) * 2);   // fc1' + fc2 (+ the next layer's q / k / v panel)
     lo[i].uqkv = take(3 * d * 4);
     lo[i].cbqkv = take(3 * d * 4);
     lo[i].u1 = take(F * 4);
@@ -316,8 +318,15 @@ static int pack_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_
       GWW_TRY(launch_scale_copy(L.fc2_b, w.b2, d, 1.f, s));
       GWW_TRY(launch_transpose_bf16(w.w2, w.w2T, d, F, s));
     }
-    // the fused-MLP weight stream holds the folded fc1 panel and fc2
-    if ((m & 12u) && d == 384 && F % 128 == 0 && F <= 1536) GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, w.wmlp, d, F, s));
+  }
+  // the fused-MLP weight stream of layer i: folded fc1 panel, fc2 and the folded q / k / v panel of layer i + 1
+  if (d == 384 && F % 128 == 0 && F <= 1536) {
+    for (int i = 0; i < n_layers; ++i) {
+      const unsigned m = dirty ? dirty[i] : 15u, mn = i + 1 < n_layers ? (dirty ? dirty[i + 1] : 15u) : 0u;
+      if (!(m & 12u) && !(mn & 1u)) continue;
+      LayerW& w = e->layers[i];
+      GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, i + 1 < n_layers ? e->layers[i + 1].wqkv_ln : nullptr, w.wmlp, d, F, 3 * d, s));
+    }
   }
   return GWW_OK;
 }
@@ -471,6 +480,8 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   static const int generic_mask = getenv("GWW_GENERIC_PATH") ? atoi(getenv("GWW_GENERIC_PATH")) : 0;
   const bool astat = bf && (d == 384 || d == 512) && F % 128 == 0 && !(generic_mask & 1);
   const bool mlp_fused = astat && d == 384 && F <= 1536 && !(generic_mask & 8);   // bit 3 = separate fc1 / fc2 kernels
+  const bool fuse_qkv = mlp_fused && !(generic_mask & 16);                          // bit 4 = stand-alone LN1 + QKV kernels
+  bool qkv_done = false;
   if (bf && d % 128 == 0 && !(generic_mask & 2))
     TR(TR_CONV1, launch_gemm_astat(melT, C, nullptr, nullptr, nullptr, nullptr, e->c1w, e->c1b, c1,
                                    (long)B * (Tin + 2), d, kConv1Kpad, EPI_CONV1, Tin + 2, s));
@@ -492,12 +503,25 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
     void* d2 = base + w.d2;
     for (int i = 0; i < e->cfg.n_layers; ++i) {
       const LayerW& L = e->layers[i];
-      TR(TR_QKV, launch_gemm_astat(xc, d, pending, pending ? xn : nullptr, L.uqkv, L.cbqkv, L.wqkv_ln, nullptr, qkv, M,
-                                   3 * d, d, EPI_BIAS, 0, s));
-      if (pending) { float* t = xc; xc = xn; xn = t; }
+      if (!qkv_done) {
+        TR(TR_QKV, launch_gemm_astat(xc, d, pending, pending ? xn : nullptr, L.uqkv, L.cbqkv, L.wqkv_ln, nullptr, qkv, M,
+                                     3 * d, d, EPI_BIAS, 0, s));
+        if (pending) { float* t = xc; xc = xn; xn = t; }
+      }
+      qkv_done = false;
       if (i == 0 && skew_event) GWW_HIP(hipEventRecord(skew_event, s));   // the other half batch starts here
       TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s));
       TR(TR_OUT, launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, L.wo, L.bo, d1, M, d, d, EPI_BIAS, 0, s));
+      if (mlp_fused && fuse_qkv && i + 1 < e->cfg.n_layers) {
+        // ... and the next layer's LN1 + q / k / v projection appended: xn receives x_next (no delta pending)
+        const LayerW& Ln = e->layers[i + 1];
+        TR(TR_MLP, launch_mlp_fused(xc, d1, xn, L.u1, L.cb1, L.wmlp, L.b2, nullptr, M, d, F, s, Ln.uqkv, Ln.cbqkv, qkv,
+                                    3 * d));
+        { float* t = xc; xc = xn; xn = t; }
+        pending = nullptr;
+        qkv_done = true;
+        continue;
+      }
       if (mlp_fused) {
         // LN2 + fc1 + GELU + fc2 in one kernel: the [M, ffn] activation never leaves the CU
         TR(TR_MLP, launch_mlp_fused(xc, d1, xn, L.u1, L.cb1, L.wmlp, L.b2, d2, M, d, F, s));

@@ -92,13 +92,21 @@ __device__ unsigned long long g_stamp_mlp[24];
 #endif
 }  // namespace
 
+// QKV = true appends the NEXT layer's  LayerNorm1 + q / k / v projection  to the block: the epilogue turns into the
+// prologue of a second A-stationary GEMM (x_next = x_new + out is formed, written back over x_new and normalised
+// while the output is still in registers; the 192 output-accumulator registers are free by then), whose weight
+// tiles simply continue the same stream.  The standalone LN+QKV kernel's 10 B/element HBM round trip of the
+// residual stream disappears.
+template <bool QKV>
 __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, const unsigned short* delta, float* x_out,
                                                             const float* __restrict__ ln_u,
                                                             const float* __restrict__ ln_cb,
                                                             const unsigned short* __restrict__ Wt,
                                                             const float* __restrict__ b2,
                                                             unsigned short* __restrict__ C, long M, int F,
-                                                            int stagger_ticks) {
+                                                            int stagger_ticks, const float* __restrict__ q_u,
+                                                            const float* __restrict__ q_cb,
+                                                            unsigned short* __restrict__ q_out, int NQ) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[MF_LDS];
   float* lds_cb = reinterpret_cast<float*>(lds + MF_OFF_CB);
   float* lds_u = reinterpret_cast<float*>(lds + MF_OFF_U);
@@ -255,6 +263,10 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   for (int j = 0; j < 8; ++j) off1[j] = r * 256 + ((((j >> 2) * 8 + 4 * hh + (j & 3)) ^ (r & 15)) << 4);
 #pragma unroll
   for (int j = 0; j < 4; ++j) off2[j] = r * 128 + (((2 * j + hh) ^ ((r >> 1) & 7)) << 4);
+  //   QKV tile [128 n][64 k], 128-byte rows, same swizzle as fc2; k-step j of the tile: chunk 4 hh + j
+  int offq[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) offq[j] = r * 128 + (((4 * hh + j) ^ ((r >> 1) & 7)) << 4);
 
   f32x16 sacc[4], oacc[MF_OT];
 #pragma unroll
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     return u * 4096 + off2[sub];
   };
 
-  const int total = nch * MF_TPC;
+  const int total = nch * MF_TPC + (QKV ? (NQ / 128) * MF_KT : 0);   // tiles in the weight stream
   int stage = 0;   // ring stage of the tile being computed
   for (int c = 0; c < nch; ++c) {
 #pragma unroll
@@ -341,6 +353,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         const int nidx = sub == 3 ? (idx + 1 == MF_TPC ? 0 : idx + 1) : idx;
         const int nsub = (sub + 1) & 3;
         const unsigned char* Wn = lds + (sub == 3 ? stage_next : stage) * MF_TILE;
+        const bool to_qkv = QKV && c == nch - 1 && idx == MF_TPC - 1 && sub == 3;   // next step = first QKV step
         // GELU piece riding in this step: two steps out of three in tiles 3..8
         int piece = -1;
         if (idx >= 3 && idx < 9) {
@@ -371,7 +384,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
             oacc[4 * ng + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                 cur[u], __builtin_bit_cast(bf16x8, pf[2 * kh + (sub >> 1)][sub & 1]), oacc[4 * ng + u], 0, 0, 0);
           }
-          if (!(GWW_MF_EXP & 4)) nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + frag_off(nidx, nsub, u));
+          if (!(GWW_MF_EXP & 4)) nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + (to_qkv ? u * 4096 + offq[0] : frag_off(nidx, nsub, u)));
         }
         // pipeline of the step: MFMA, fragment read, a slice of the VALU work -- four times
         if (piece >= 0) {
@@ -407,29 +420,191 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       MSTAMP(8 + idx);
     }
   }
-  mf_wait_vmcnt<0>();   // the re-reads issued past the end
-
-  // ---- epilogue: + b2 -> bf16 -> wave-private LDS transpose -> whole-line stores
+  if constexpr (!QKV) {
+    mf_wait_vmcnt<0>();   // the re-reads issued past the end
+    // ---- epilogue: + b2 -> bf16 -> wave-private LDS transpose -> whole-line stores
 #pragma unroll
-  for (int np = 0; np < MF_OT / 2; ++np) {
+    for (int np = 0; np < MF_OT / 2; ++np) {
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int t = 2 * np + tt;
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * np + tt;
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int nl = 32 * t + 8 * cc + 4 * hh;
-        const float4 bv = *reinterpret_cast<const float4*>(lds_b2 + nl);
-        u32x2 o = {pack2bf(oacc[t][4 * cc] + bv.x, oacc[t][4 * cc + 1] + bv.y),
-                   pack2bf(oacc[t][4 * cc + 2] + bv.z, oacc[t][4 * cc + 3] + bv.w)};
-        *reinterpret_cast<u32x2*>(slice + r * MF_SLICE_STRIDE + (32 * tt + 8 * cc + 4 * hh) * 2) = o;
+        for (int cc = 0; cc < 4; ++cc) {
+          const int nl = 32 * t + 8 * cc + 4 * hh;
+          const float4 bv = *reinterpret_cast<const float4*>(lds_b2 + nl);
+          u32x2 o = {pack2bf(oacc[t][4 * cc] + bv.x, oacc[t][4 * cc + 1] + bv.y),
+                     pack2bf(oacc[t][4 * cc + 2] + bv.z, oacc[t][4 * cc + 3] + bv.w)};
+          *reinterpret_cast<u32x2*>(slice + r * MF_SLICE_STRIDE + (32 * tt + 8 * cc + 4 * hh) * 2) = o;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4 u = *reinterpret_cast<const u32x4*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + cchunk * 16);
+        const long orow = m_base + 8 * i + crow;
+        *reinterpret_cast<u32x4*>(C + orow * MF_D + np * 64 + 8 * cchunk) = u;
       }
     }
+  } else {
+    // ---- epilogue == prologue of the next layer's LN1 + QKV GEMM.  Per 64-column chunk np: the fc2 output (+ b2,
+    // rounded to bf16 exactly like the stand-alone kernel's delta) goes through the wave-private slice into row
+    // order, x_next = x_new + out is formed from whole-line re-reads of x_new (written by this wave in the
+    // prologue), written back IN PLACE, and shifted / measured / packed into the A fragments of k-tile np.
+    // The tiles already in flight are older than these loads: hipcc's own vmcnt waits retire them first.
+    {
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, cshift[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const u32x4 u = *reinterpret_cast<const u32x4*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + cchunk * 16);
-      const long orow = m_base + 8 * i + crow;
-      *reinterpret_cast<u32x4*>(C + orow * MF_D + np * 64 + 8 * cchunk) = u;
+      for (int np = 0; np < MF_KT; ++np) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * np + tt;
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int nl = 32 * t + 8 * cc + 4 * hh;
+            const float4 bv = *reinterpret_cast<const float4*>(lds_b2 + nl);
+            u32x2 o = {pack2bf(oacc[t][4 * cc] + bv.x, oacc[t][4 * cc + 1] + bv.y),
+                       pack2bf(oacc[t][4 * cc + 2] + bv.z, oacc[t][4 * cc + 3] + bv.w)};
+            *reinterpret_cast<u32x2*>(slice + r * MF_SLICE_STRIDE + (32 * tt + 8 * cc + 4 * hh) * 2) = o;
+          }
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float* xp = x_out + grow[i] * MF_D + 64 * np + 32 * h2 + 4 * cchunk;
+            f32x4 v = *reinterpret_cast<const f32x4*>(xp);
+            const u32x2 dv = *reinterpret_cast<const u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8);
+            v[0] += bf2f((unsigned short)(dv[0] & 0xffff));
+            v[1] += bf2f((unsigned short)(dv[0] >> 16));
+            v[2] += bf2f((unsigned short)(dv[1] & 0xffff));
+            v[3] += bf2f((unsigned short)(dv[1] >> 16));
+            // rows past M are clamped duplicates of row M - 1: only the real row may update in place
+            if (m_base + 8 * i + crow < M) *reinterpret_cast<f32x4*>(xp) = v;
+            if (np == 0 && h2 == 0) {
+              float t = (v[0] + v[1]) + (v[2] + v[3]);
+              t += __shfl_xor(t, 1, 64);
+              t += __shfl_xor(t, 2, 64);
+              t += __shfl_xor(t, 4, 64);
+              cshift[i] = t * (1.0f / 32.0f);
+            }
+            v[0] -= cshift[i]; v[1] -= cshift[i]; v[2] -= cshift[i]; v[3] -= cshift[i];
+            s1[i] += (v[0] + v[1]) + (v[2] + v[3]);
+            s2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8) = o;
+          }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          u32x4 u = *reinterpret_cast<const u32x4*>(slice + r * MF_SLICE_STRIDE + (4 * hh + j) * 16);
+          asm volatile("" : "+v"(u)::"memory");
+          af[4 * np + j] = __builtin_bit_cast(bf16x8, u);
+        }
+      }
+      float* stat = reinterpret_cast<float*>(slice);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a = s1[i], b = s2[i];
+        a += __shfl_xor(a, 1, 64); b += __shfl_xor(b, 1, 64);
+        a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64);
+        a += __shfl_xor(a, 4, 64); b += __shfl_xor(b, 4, 64);
+        const float mean = a * (1.0f / MF_D);
+        const float var = fmaxf(b * (1.0f / MF_D) - mean * mean, 0.f);
+        if (cchunk == 0) {
+          stat[8 * i + crow] = rsqrtf(var + 1e-5f);
+          stat[32 + 8 * i + crow] = mean;
+        }
+      }
+      row_rstd = stat[r];
+      row_mean = stat[32 + r];
+      asm volatile("" : "+v"(row_rstd), "+v"(row_mean)::"memory");
     }
+    // u / cb of the QKV panel replace fc1's (every wave is past its last GELU piece: those end three tiles, i.e.
+    // three barriers, before the loop exit)
+    for (int i = tid; i < NQ; i += MF_THREADS) {
+      lds_cb[i] = q_cb[i];
+      lds_u[i] = q_u[i];
+    }
+    mf_wait_vmcnt<0>();               // x_next stores retired, every tile issued so far has landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();     // ... and everybody else's; u / cb visible
+
+    // ---- second GEMM: qkv[32 rows, NQ] = LN1(x_next) Wqkv'^T, n-tiles of 128 columns, 6 k-tiles each
+    const int T0 = nch * MF_TPC;
+    f32x16 acc[4];
+    for (int nt = 0; nt < NQ / 128; ++nt) {
+#pragma unroll
+      for (int kt = 0; kt < MF_KT; ++kt) {
+        // the 8 output stores of the previous n-tile are younger than the DMA group being waited for while
+        // kt <= 4 (that group was issued 5 tiles ago): allow them to stay in flight
+        if (nt > 0 && kt != MF_KT - 1) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + 8>();
+        else mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
+        __builtin_amdgcn_s_barrier();
+        const int it = T0 + nt * MF_KT + kt;
+        const int dma_tile = it + MF_AHEAD < total ? it + MF_AHEAD : total - 1;
+        const int dma_stage = stage + MF_AHEAD >= MF_NST ? stage + MF_AHEAD - MF_NST : stage + MF_AHEAD;
+        const int stage_next = stage + 1 == MF_NST ? 0 : stage + 1;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const int q = 4 * kt + sub;
+          bf16x8(&cur)[4] = wf[q & 1];
+          bf16x8(&nxt)[4] = wf[(q + 1) & 1];
+          const unsigned char* Wn = lds + (sub == 3 ? stage_next : stage) * MF_TILE + offq[(sub + 1) & 3];
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(dma_tile, dma_stage, sub);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (kt == 0 && sub == 0) {
+              f32x16 z;
+#pragma unroll
+              for (int j = 0; j < 16; ++j) z[j] = 0.f;
+              acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[u], af[4 * kt + sub], z, 0, 0, 0);
+            } else {
+              acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[u], af[4 * kt + sub], acc[u], 0, 0, 0);
+            }
+            nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + u * 4096);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        stage = stage_next;
+      }
+      // n-tile epilogue: LayerNorm algebra + bias -> bf16 -> slice transpose -> whole-line stores (8 per wave)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * half + tt;
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int nl = 128 * nt + 32 * t + 8 * cc + 4 * hh;
+            const float4 uv = *reinterpret_cast<const float4*>(lds_u + nl);
+            const float4 bv = *reinterpret_cast<const float4*>(lds_cb + nl);
+            const float v0 = fmaf(row_rstd, fmaf(-row_mean, uv.x, acc[t][4 * cc]), bv.x);
+            const float v1 = fmaf(row_rstd, fmaf(-row_mean, uv.y, acc[t][4 * cc + 1]), bv.y);
+            const float v2 = fmaf(row_rstd, fmaf(-row_mean, uv.z, acc[t][4 * cc + 2]), bv.z);
+            const float v3 = fmaf(row_rstd, fmaf(-row_mean, uv.w, acc[t][4 * cc + 3]), bv.w);
+            u32x2 o = {pack2bf(v0, v1), pack2bf(v2, v3)};
+            *reinterpret_cast<u32x2*>(slice + r * MF_SLICE_STRIDE + (32 * tt + 8 * cc + 4 * hh) * 2) = o;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const u32x4 u = *reinterpret_cast<const u32x4*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + cchunk * 16);
+          const long orow = m_base + 8 * i + crow;
+          *reinterpret_cast<u32x4*>(q_out + orow * NQ + nt * 128 + 64 * half + 8 * cchunk) = u;
+        }
+      }
+    }
+    mf_wait_vmcnt<0>();   // the re-reads issued past the end
   }
   MSTAMP(3);
   MSTAMP_FLUSH
@@ -442,15 +617,23 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 //   idx >= 6: i2 = idx - 6, kh = i2 / 3, ng = i2 % 3: [128 rows][64 k] = W2[128 ng + row][128 c + 64 kh + swap23(k)];
 //             chunks XOR-swizzled by (row >> 1) & 7
 // swap23 exchanges bits 2 and 3 of k: the operand order of the accumulator-as-operand product (header).
+// Optionally followed by the NEXT layer's LayerNorm-folded q / k / v panel (k_mlp_fused<true>): n-tile major,
+// six [128 n][64 k] images per n-tile, chunks XOR-swizzled by (row >> 1) & 7.
 __global__ __launch_bounds__(256) void k_mlp_pack(const unsigned short* __restrict__ w1,
                                                   const unsigned short* __restrict__ w2,
+                                                  const unsigned short* __restrict__ wq,
                                                   unsigned short* __restrict__ out, int F, long n_chunks16) {
+  const int mlp_tiles = (F / 128) * MF_TPC;
   for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < n_chunks16; g += (long)gridDim.x * 256) {
     const int tile = (int)(g >> 10), within = (int)(g & 1023);
     const int row = within >> 3, chunk = (within & 7) ^ ((row >> 1) & 7);
     const int c = tile / MF_TPC, idx = tile - c * MF_TPC;
     u32x4 v;
-    if (idx < MF_KT) {
+    if (tile >= mlp_tiles) {
+      // appended LN1-folded q / k / v panel [NQ, 384]: n-tile major, 6 k-tiles each, [128 n][64 k] images
+      const int it2 = tile - mlp_tiles, nt = it2 / MF_KT, kt = it2 - nt * MF_KT;
+      v = *reinterpret_cast<const u32x4*>(wq + (long)(128 * nt + row) * MF_D + 64 * kt + 8 * chunk);
+    } else if (idx < MF_KT) {
       // [64 n][128 k] image: 16 chunks per row, chunk ch stored at ch ^ (row & 15)
       const int row2 = within >> 4, ch = (within & 15) ^ (row2 & 15);
       const int nh = idx / 3, kt3 = idx - 3 * nh;
@@ -471,12 +654,15 @@ __global__ __launch_bounds__(256) void k_mlp_pack(const unsigned short* __restri
   }
 }
 
-// w1_folded bf16 [F, 384], w2 bf16 [384, F] -> out bf16, 2 * 384 * F elements
-int launch_mlp_pack(const void* w1_folded, const void* w2, void* out, int d, int F, hipStream_t s) {
+// w1_folded bf16 [F, 384], w2 bf16 [384, F] (+ wqkv_folded bf16 [NQ, 384] or NULL) -> out bf16,
+// 2 * 384 * F (+ NQ * 384) elements
+int launch_mlp_pack(const void* w1_folded, const void* w2, const void* wqkv_folded, void* out, int d, int F, int NQ,
+                    hipStream_t s) {
   GWW_REQUIRE(d == MF_D && F % 128 == 0 && F > 0, "mlp_pack: d must be 384 and ffn a multiple of 128");
-  const long n16 = 2L * MF_D * F / 8;
+  GWW_REQUIRE(!wqkv_folded || (NQ > 0 && NQ % 128 == 0), "mlp_pack: the q / k / v panel needs NQ %% 128 == 0");
+  const long n16 = (2L * MF_D * F + (wqkv_folded ? (long)NQ * MF_D : 0)) / 8;
   hipLaunchKernelGGL(k_mlp_pack, dim3((unsigned)cdiv(n16, 256)), dim3(256), 0, s, (const unsigned short*)w1_folded,
-                     (const unsigned short*)w2, (unsigned short*)out, F, n16);
+                     (const unsigned short*)w2, (const unsigned short*)wqkv_folded, (unsigned short*)out, F, n16);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }
@@ -485,20 +671,31 @@ int launch_mlp_pack(const void* w1_folded, const void* w2, void* out, int d, int
 // panel and the fc2 panel, ln_u / ln_cb from gww_ln_fold_weights; C bf16 [>= roundup(M, 128), 384] (whole
 // 128-row panels are stored).
 int launch_mlp_fused(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
-                     const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s) {
-  GWW_REQUIRE(x && delta && x_out && ln_u && ln_cb && Wt && b2 && C, "mlp_fused: NULL operand");
+                     const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s,
+                     const float* q_u, const float* q_cb, void* q_out, int NQ) {
+  GWW_REQUIRE(x && delta && x_out && ln_u && ln_cb && Wt && b2, "mlp_fused: NULL operand");
   GWW_REQUIRE(d == MF_D, "mlp_fused: built for d_model = 384 (got %d)", d);
   GWW_REQUIRE(F % 128 == 0 && F > 0 && F <= MF_FMAX, "mlp_fused: ffn = %d must be a multiple of 128, <= 1536", F);
   GWW_REQUIRE((const void*)x_out != (const void*)x, "mlp_fused: x_out must not alias x");
-  GWW_REQUIRE(((((uintptr_t)x) | ((uintptr_t)delta) | ((uintptr_t)x_out) | ((uintptr_t)Wt) | ((uintptr_t)C)) & 15) == 0,
-              "mlp_fused: operands must be 16-byte aligned");
+  const bool qkv = q_out != nullptr;
+  GWW_REQUIRE(qkv || C, "mlp_fused: no output");
+  GWW_REQUIRE(!qkv || (q_u && q_cb && NQ > 0 && NQ % 128 == 0 && NQ <= MF_FMAX),
+              "mlp_fused: the fused q / k / v projection needs u, cb and NQ %% 128 == 0, NQ <= 1536");
+  GWW_REQUIRE(((((uintptr_t)x) | ((uintptr_t)delta) | ((uintptr_t)x_out) | ((uintptr_t)Wt) | ((uintptr_t)C) |
+                ((uintptr_t)q_out)) & 15) == 0, "mlp_fused: operands must be 16-byte aligned");
   if (M == 0) return GWW_OK;
   const long panels = cdiv(M, MF_BM);
   // stagger only when there is more than one round of workgroups to keep de-phased; 100 MHz ticks
-  static const int stagger_env = getenv("GWW_MLP_STAGGER") ? atoi(getenv("GWW_MLP_STAGGER")) : -1;
-  const int stagger = panels >= 512 ? (stagger_env >= 0 ? stagger_env : 500 * F / 1536) : 0;
-  hipLaunchKernelGGL(k_mlp_fused, dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta,
-                     x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger);
+  static const int stagger_env = getenv("GWW_MLP_STAGGER") ? atoi(getenv("GWW_MLP_STAGGER")) : 0;
+  const int stagger = panels >= 512 ? stagger_env : 0;
+  if (qkv)
+    hipLaunchKernelGGL(k_mlp_fused<true>, dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta,
+                       x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger, q_u, q_cb,
+                       (unsigned short*)q_out, NQ);
+  else
+    hipLaunchKernelGGL(k_mlp_fused<false>, dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta,
+                       x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger, nullptr,
+                       nullptr, nullptr, 0);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }
@@ -518,13 +715,16 @@ extern "C" int gww_debug_stamps_mlp(unsigned long long* out8, int reset) {
 }
 #endif
 
-extern "C" int gww_mlp_pack_bf16(const void* w1_folded, const void* w2, void* out, int d, int F, void* stream) {
+extern "C" int gww_mlp_pack_bf16(const void* w1_folded, const void* w2, const void* wqkv_folded_or_null, void* out, int d,
+                                 int F, int NQ, void* stream) {
   GWW_REQUIRE(w1_folded && w2 && out, "gww_mlp_pack_bf16: NULL argument");
-  return launch_mlp_pack(w1_folded, w2, out, d, F, (hipStream_t)stream);
+  return launch_mlp_pack(w1_folded, w2, wqkv_folded_or_null, out, d, F, NQ, (hipStream_t)stream);
 }
 
 extern "C" int gww_mlp_fused_bf16(const float* x, const void* delta, float* x_out, const float* ln_u,
                                   const float* ln_cb, const void* Wt, const float* b2, void* C, long M, int d,
-                                  int F, void* stream) {
-  return launch_mlp_fused(x, delta, x_out, ln_u, ln_cb, Wt, b2, C, M, d, F, (hipStream_t)stream);
+                                  int F, const float* qkv_u, const float* qkv_cb, void* qkv_out, int NQ,
+                                  void* stream) {
+  return launch_mlp_fused(x, delta, x_out, ln_u, ln_cb, Wt, b2, C, M, d, F, (hipStream_t)stream, qkv_u, qkv_cb, qkv_out,
+                          NQ);
 }

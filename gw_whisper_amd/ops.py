@@ -163,35 +163,51 @@ def gemm_fulln(a: torch.Tensor, w: torch.Tensor, bias=None, epilogue: int = 0) -
     return c[:M]
 
 
-def mlp_pack(w1_folded: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
-    """Weight stream of mlp_fused: folded fc1 panel [F, 384] + fc2 panel [384, F] -> bf16 [2 * 384 * F]."""
+def mlp_pack(w1_folded: torch.Tensor, w2: torch.Tensor, wqkv_folded: torch.Tensor | None = None) -> torch.Tensor:
+    """Weight stream of mlp_fused: folded fc1 panel [F, 384] + fc2 panel [384, F] (+ the next layer's folded
+    q / k / v panel [NQ, 384]) -> bf16 [2 * 384 * F (+ NQ * 384)]."""
     w1 = _dev(w1_folded, torch.bfloat16, "W1")
     w2 = _dev(w2, torch.bfloat16, "W2")
+    wq = _dev(wqkv_folded, torch.bfloat16, "Wqkv") if wqkv_folded is not None else None
     F, d = w1.shape
-    out = torch.empty((2 * d * F,), dtype=torch.bfloat16, device=w1.device)
+    NQ = wq.shape[0] if wq is not None else 0
+    out = torch.empty((2 * d * F + NQ * d,), dtype=torch.bfloat16, device=w1.device)
     with torch.cuda.device(w1.device):
-        check(lib().gww_mlp_pack_bf16(w1.data_ptr(), w2.data_ptr(), out.data_ptr(), d, F, _stream()),
-              "gww_mlp_pack_bf16")
+        check(lib().gww_mlp_pack_bf16(w1.data_ptr(), w2.data_ptr(), wq.data_ptr() if wq is not None else None,
+                                      out.data_ptr(), d, F, NQ, _stream()), "gww_mlp_pack_bf16")
     return out
 
 
-def mlp_fused(x, delta, wt, ln_u, ln_cb, b2):
-    """(C bf16 [M, 384], x_new fp32 [M, 384]) = fused LayerNorm -> fc1 -> GELU -> fc2 of x + delta."""
+def mlp_fused(x, delta, wt, ln_u, ln_cb, b2, qkv=None):
+    """(C bf16 [M, 384], x_new fp32 [M, 384]) = fused LayerNorm -> fc1 -> GELU -> fc2 of x + delta.
+    ``qkv=(u, cb)`` of the next layer's folded q / k / v projection (panel appended to ``wt``): returns
+    (qkv bf16 [M, NQ], x_next fp32 [M, 384]) instead, x_next = x + delta + bf16(mlp output)."""
     x = _dev(x, torch.float32, "x")
     delta = _dev(delta, torch.bfloat16, "delta")
     wt = _dev(wt, torch.bfloat16, "Wt")
     M, d = x.shape
     F = ln_u.numel()
     Mp = (M + 127) // 128 * 128
-    c = torch.empty((Mp, d), dtype=torch.bfloat16, device=x.device)
     x_out = torch.empty_like(x)
     f = lambda t: _dev(t, torch.float32)
     u, cb, b2 = f(ln_u), f(ln_cb), f(b2)
+    if qkv is None:
+        c = torch.empty((Mp, d), dtype=torch.bfloat16, device=x.device)
+        qu = qc = qo = None
+        NQ = 0
+    else:
+        qu, qc = f(qkv[0]), f(qkv[1])
+        NQ = qu.numel()
+        qo = torch.empty((Mp, NQ), dtype=torch.bfloat16, device=x.device)
+        c = None
     with torch.cuda.device(x.device):
         check(lib().gww_mlp_fused_bf16(x.data_ptr(), delta.data_ptr(), x_out.data_ptr(), u.data_ptr(), cb.data_ptr(),
-                                       wt.data_ptr(), b2.data_ptr(), c.data_ptr(), M, d, F, _stream()),
+                                       wt.data_ptr(), b2.data_ptr(), c.data_ptr() if c is not None else None, M, d, F,
+                                       qu.data_ptr() if qu is not None else None,
+                                       qc.data_ptr() if qc is not None else None,
+                                       qo.data_ptr() if qo is not None else None, NQ, _stream()),
               "gww_mlp_fused_bf16")
-    return c[:M], x_out
+    return ((c if qkv is None else qo)[:M], x_out)
 
 
 def attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:

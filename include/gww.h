@@ -223,14 +223,22 @@ int gww_gemm_fulln_bf16(const void* A, const void* W, const float* bias, void* C
 /* Fused MLP block at d_model = 384 (HF:modeling_whisper.py:401-407, residual add deferred to the consumer):
  *   x_out = x + delta;   C = bf16( fc2( gelu( fc1( LayerNorm(x_out) ) ) ) + b2 )
  * x fp32 [M,384], delta bf16 [M,384], x_out fp32 [M,384] (must not alias x); ln_u / ln_cb [F] from
- * gww_ln_fold_weights of fc1; Wt = gww_mlp_pack_bf16 of the folded fc1 panel and the fc2 panel; C bf16 with rows
- * allocated up to the next multiple of 128.  F % 128 == 0, F <= 1536.  The [M,F] activation never leaves the CU;
- * GELU is x * sigmoid(odd quintic), |err| <= 2.6e-5 against the erf form. */
+ * gww_ln_fold_weights of fc1; Wt = gww_mlp_pack_bf16 stream; C bf16 with rows allocated up to the next multiple of
+ * 128.  F % 128 == 0, F <= 1536.  The [M,F] activation never leaves the CU; GELU is x * sigmoid(odd quintic),
+ * |err| <= 2.6e-5 against the erf form.
+ * With qkv_out != NULL the NEXT layer's self_attn_layer_norm + q / k / v projection (HF:modeling_whisper.py:392,
+ * 303-318) is appended: x_out then receives x_next = x + delta + bf16(C) (the residual stream entering the next
+ * layer), C is not written, and qkv_out bf16 [M (rows padded to 128), NQ] = LayerNorm(x_next) Wqkv'^T + cb with
+ * qkv_u / qkv_cb from gww_ln_fold_weights of that projection (its panel appended to the stream by
+ * gww_mlp_pack_bf16).  NQ % 128 == 0, NQ <= 1536. */
 int gww_mlp_fused_bf16(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
-                       const void* Wt, const float* b2, void* C, long M, int d, int F, void* stream);
-/* Pre-tile the weights of gww_mlp_fused_bf16: w1_folded bf16 [F,384] (gww_ln_fold_weights), w2 bf16 [384,F]
- * -> out bf16, 2*384*F elements, as the sequence of swizzled 16-KiB LDS images the kernel streams. */
-int gww_mlp_pack_bf16(const void* w1_folded, const void* w2, void* out, int d, int F, void* stream);
+                       const void* Wt, const float* b2, void* C, long M, int d, int F, const float* qkv_u,
+                       const float* qkv_cb, void* qkv_out, int NQ, void* stream);
+/* Pre-tile the weights of gww_mlp_fused_bf16: w1_folded bf16 [F,384] (gww_ln_fold_weights), w2 bf16 [384,F],
+ * optionally the next layer's folded q / k / v panel bf16 [NQ,384] -> out bf16, 2*384*F (+ NQ*384) elements, as the
+ * sequence of swizzled 16-KiB LDS images the kernel streams. */
+int gww_mlp_pack_bf16(const void* w1_folded, const void* w2, const void* wqkv_folded_or_null, void* out, int d, int F,
+                      int NQ, void* stream);
 /* Q-transform front end #2 (ml4gw QScan as used by MLGWSC-1/train.py:117-122,135-154; PARITY UNPINNED: ml4gw is not
  * vendored, pinned or installed -- the kernels follow oracle/qscan.py).  The host builds the static tiling once
  * (gw_whisper_amd/qscan.py): rows = int [n_rows][6] (plane, ntiles, windowsize, first data index, energy offset,

@@ -358,3 +358,39 @@ def test_mlp_fused(T, gww, M, F):
     # bf16 operands twice (K = 384, then K = F) + bf16 output
     np.testing.assert_allclose(got, ref, atol=4e-2, rtol=2 ** -7)
     assert np.sqrt(((got - ref) ** 2).mean()) < 8e-3
+
+
+@pytest.mark.parametrize("M", [128, 1500, 4000])
+def test_mlp_fused_with_next_layers_qkv(T, gww, M):
+    """mlp_fused with the NEXT layer's LayerNorm1 + q / k / v projection appended: x_next = x + delta + bf16(mlp),
+    qkv = Linear_qkv(LayerNorm1(x_next)) -- against fp64 (HF:modeling_whisper.py:392-407 across the layer seam)."""
+    from gw_whisper_amd import ops
+    d, F, NQ = 384, 1536, 1152
+    rng = np.random.default_rng(M)
+    x = (rng.standard_normal((M, d)) * 2 + 0.3).astype(np.float32)
+    x[::7] += 25.0
+    dl = _bf(rng.standard_normal((M, d)) * 0.5)
+    g = lambda n: (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    sm = lambda n: (0.1 * rng.standard_normal(n)).astype(np.float32)
+    lw, lb, lw1, lb1 = g(d), sm(d), g(d), sm(d)
+    w1 = (rng.standard_normal((F, d)) / np.sqrt(d)).astype(np.float32)
+    b1 = rng.standard_normal(F).astype(np.float32)
+    w2 = (rng.standard_normal((d, F)) / np.sqrt(F)).astype(np.float32)
+    b2 = rng.standard_normal(d).astype(np.float32)
+    wq = (rng.standard_normal((NQ, d)) / np.sqrt(d)).astype(np.float32)
+    bq = rng.standard_normal(NQ).astype(np.float32)
+    c = lambda a: T.from_numpy(np.asarray(a)).cuda()
+    w1f, u, cb = ops.ln_fold_weights(c(w1), c(lw), c(lb), c(b1))
+    wqf, uq, cq = ops.ln_fold_weights(c(wq), c(lw1), c(lb1), c(bq))
+    wt = ops.mlp_pack(w1f, c(w2).bfloat16(), wqf)
+    qkv, x_next = ops.mlp_fused(c(x), c(dl).bfloat16(), wt, u, cb, c(b2), qkv=(uq, cq))
+    # reference: the MLP delta exactly as the stand-alone kernel emits it (bf16), then the seam in fp64
+    wt0 = ops.mlp_pack(w1f, c(w2).bfloat16())
+    delta2, x_new = ops.mlp_fused(c(x), c(dl).bfloat16(), wt0, u, cb, c(b2))
+    xn = x_new.cpu().numpy().astype(np.float64) + delta2.float().cpu().numpy().astype(np.float64)
+    got_x = x_next.cpu().numpy()
+    np.testing.assert_allclose(got_x, xn, atol=2e-5, rtol=1e-6)            # same bf16 delta, one fp32 add
+    ref = oenc.layer_norm(got_x.astype(np.float64), lw1, lb1) @ wq.astype(np.float64).T + bq
+    got = qkv.float().cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=3e-2, rtol=2 ** -7)
+    assert np.sqrt(((got - ref) ** 2).mean()) < 6e-3
