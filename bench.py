@@ -334,6 +334,9 @@ def main():
                 "fc2": (B * 2 * T_TOK * d * ffn, M * (ffn + d) * es),
                 "final_layernorm": (0, M * d * 8),
                 "mlp_fused(ln+fc1+gelu+fc2)": (B * 4 * T_TOK * d * ffn, M * d * (4 + 2 + 4 + 2)),
+                # + the next layer's LN1 + q/k/v: x, delta in; x_next (written twice: x_new, then in place) and qkv out
+                "mlp_fused+next_ln_qkv": (B * (4 * T_TOK * d * ffn + 2 * T_TOK * d * 3 * d),
+                                          M * d * (4 + 2 + 4 + 4 + 4) + M * 3 * d * 2),
             }
             rows = []
             for name, (ms, cnt) in traced.items():

@@ -20,9 +20,32 @@
 // fp32 kernel: same dataflow on v_mfma_f32_32x32x2_f32 (exact fp32), 32-key tiles.
 #include "common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace gww {
+
+#ifdef GWW_STAMP
+__device__ unsigned long long g_stamp_att[8];
+#define ASTAMP_DECL unsigned long long _t0 = __builtin_amdgcn_s_memtime(); unsigned long long _acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#define ASTAMP(i)                                                  \
+  do {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    const unsigned long long _t1 = __builtin_amdgcn_s_memtime();   \
+    _acc[i] += _t1 - _t0;                                          \
+    _t0 = _t1;                                                     \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+#define ASTAMP_FLUSH                                                                 \
+  if (lane == 0) {                                                                   \
+    for (int _q = 0; _q < 7; ++_q) atomicAdd(&g_stamp_att[_q], _acc[_q]);            \
+    atomicAdd(&g_stamp_att[7], 1ull);                                                \
+  }
+#else
+#define ASTAMP_DECL
+#define ASTAMP(i)
+#define ASTAMP_FLUSH
+#endif
 
 constexpr int DH = 64;
 constexpr int QB = 128;   // query rows per workgroup
@@ -38,7 +61,11 @@ __device__ __forceinline__ bf16x8 cvt8(const f32x16& a, int base) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short* __restrict__ qkv,
+// NW waves x 32 query rows per workgroup.  NW = 8 (256 rows, one workgroup per CU) streams every K / V tile
+// once per 256 queries: at 128 rows per workgroup the kernel needed 32 B/clk/CU of K / V from L2 -- the whole L2
+// bandwidth of an XCD -- and spent 60 % of its cycles waiting for the next tile (tools/stamp_att.py).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attention_bf16(const unsigned short* __restrict__ qkv,
                                                            unsigned short* __restrict__ ctx,
                                                            float* __restrict__ lse, int T, int H,
                                                            int q_tiles) {
@@ -64,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
   const unsigned short* vp = base + 2 * d + h * DH;
 
   const int r = lane & 31, hh = lane >> 5;
-  const int q_row = qt * QB + wave * 32 + r;
+  const int q_row = qt * (NW * 32) + wave * 32 + r;
   const int q_ld = q_row < T ? q_row : T - 1;
 
   // Q fragments: B operand of K Q^T -> Q[q = r][dh = 16 s + 8 hh + j]
@@ -73,18 +100,19 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
   for (int s = 0; s < 4; ++s)
     qf[s] = *reinterpret_cast<const bf16x8*>(qp + (long)q_ld * row_stride + 16 * s + 8 * hh);
 
-  // staging: 2 chunks (16 B) of K and 2 of V per thread per tile
-  int st_row[2], st_chunk[2];
+  // staging: 512 chunks (16 B) of K and of V per tile, NCH per thread
+  constexpr int NCH = 512 / (NW * 64);
+  int st_row[NCH], st_chunk[NCH];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid + 256 * i;
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + NW * 64 * i;
     st_row[i] = c >> 3;
     st_chunk[i] = c & 7;
   }
-  u32x4 rk[2], rv[2];
+  u32x4 rk[NCH], rv[NCH];
   auto gload = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       int key = kt * KB + st_row[i];
       if (key >= T) key = T - 1;
       rk[i] = *reinterpret_cast<const u32x4*>(kp + (long)key * row_stride + st_chunk[i] * 8);
@@ -93,18 +121,29 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       *reinterpret_cast<u32x4*>(Ks(buf) + k_off(st_row[i], st_chunk[i])) = rk[i];
       *reinterpret_cast<u32x4*>(Vs(buf) + v_off(st_row[i], st_chunk[i] * 16)) = rv[i];
     }
   };
 
+  ASTAMP_DECL
   f32x16 ot[2];
 #pragma unroll
   for (int n = 0; n < 2; ++n)
 #pragma unroll
     for (int j = 0; j < 16; ++j) ot[n][j] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY;
+  // The softmax denominator rides on the matrix pipe: one extra MFMA per k-step multiplies P^T by an all-ones A
+  // operand, so every register of `lt` holds sum_k bf16(p[k]) of the lane's query (both key halves included) --
+  // 32 v_add_f32 per tile leave the VALU, which is the busier pipe here, for 4 MFMAs on the idler one; the
+  // normalisation then uses exactly the rounded probabilities the numerator uses.
+  f32x16 lt;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) lt[j] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
   const int n_kt = (T + KB - 1) / KB;
   gload(0);
@@ -125,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
     constexpr bool MASKED = decltype(masked_c)::value;
     const int buf = kt & 1;
     if (kt + 1 < n_kt) gload(kt + 1);
+    ASTAMP(1);
 
     // ---- S^T = K Q^T : st[g][reg] = score(key = 32 g + (reg&3) + 8 (reg>>2) + 4 hh, q = r)
     f32x16 st[2];
@@ -138,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
         st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[g], 0, 0, 0);
       }
     }
+    ASTAMP(2);
     if constexpr (MASKED) {   // keys >= T
 #pragma unroll
       for (int g = 0; g < 2; ++g)
@@ -157,25 +198,21 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
     if (__builtin_amdgcn_ballot_w64(tmax > m_run + kDefer) != 0) {   // wave-uniform
       const float m_new = fmaxf(m_run, tmax);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
-      l_run *= alpha;
       m_run = m_new;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) lt[j] *= alpha;
 #pragma unroll
       for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int j = 0; j < 16; ++j) ot[n][j] *= alpha;
     }
     const float ms = m_run * kLog2e;
-    float psum = 0.f;
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(st[g][j], kLog2e, -ms));
-        st[g][j] = p;
-        psum += p;
-      }
-    l_run += psum;
+      for (int j = 0; j < 16; ++j) st[g][j] = __builtin_amdgcn_exp2f(fmaf(st[g][j], kLog2e, -ms));
 
+    ASTAMP(3);
     // ---- O^T += V^T P^T : B operand = bf16(st) registers 8 s .. 8 s + 7 (k-step s);
     //      A operand element j <-> key 32 g + 16 s + 8 (j>>2) + 4 hh + (j&3), dh = 32 n + r
 #pragma unroll
@@ -183,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 pf = cvt8(st[g], 8 * s);
+        lt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lt, 0, 0, 0);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
           const int key0 = 32 * g + 16 * s + 4 * hh + tr_q;
@@ -199,14 +237,17 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
         }
       }
     }
+    ASTAMP(4);
     if (kt + 1 < n_kt) lstore(buf ^ 1);
+    ASTAMP(5);
     __syncthreads();
+    ASTAMP(6);
   };
   for (int kt = 0; kt + 1 < n_kt; ++kt) tile(kt, std::false_type{});
   if ((T % KB) != 0) tile(n_kt - 1, std::true_type{});
   else tile(n_kt - 1, std::false_type{});
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = lt[0];
   const float inv = 1.0f / l_tot;
   // log-sum-exp of the row (training: the backward recomputes P = exp(S - LSE))
   if (lse && q_row < T && hh == 0) lse[((long)b * H + h) * T + q_row] = m_run + __logf(l_tot);
@@ -222,6 +263,8 @@ __global__ __launch_bounds__(256, 2) void k_attention_bf16(const unsigned short*
         *reinterpret_cast<u32x2*>(orow + dh) = o;
       }
   }
+  ASTAMP(0);
+  ASTAMP_FLUSH
 }
 
 int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipStream_t s, float* lse) {
@@ -229,11 +272,19 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
   GWW_REQUIRE(B >= 0 && T > 0 && H > 0, "attention_bf16: bad shape B=%d T=%d H=%d", B, T, H);
   GWW_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)ctx) & 15) == 0, "attention_bf16: 16-byte alignment");
   if (B == 0) return GWW_OK;
-  const int q_tiles = (T + QB - 1) / QB;
+  static const int nw_env = getenv("GWW_ATT_WAVES") ? atoi(getenv("GWW_ATT_WAVES")) : 0;   // tuning aid: 4 or 8
+  // 128 query rows per workgroup, two workgroups per CU; the 256-row form (one per CU, K / V streamed once per
+  // 256 queries) measures 5 % slower at T = 1500 -- the kernel is issue-bound, not L2-bound
+  const int nw = nw_env == 8 ? 8 : 4;
+  const int q_tiles = (T + nw * 32 - 1) / (nw * 32);
   const long blocks = (long)q_tiles * B * H;
   GWW_REQUIRE(blocks < 2147483647L, "attention_bf16: grid too large");
-  hipLaunchKernelGGL(k_attention_bf16, dim3((unsigned)blocks), dim3(256), 0, s,
-                     (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles);
+  if (nw == 8)
+    hipLaunchKernelGGL(k_attention_bf16<8>, dim3((unsigned)blocks), dim3(512), 0, s,
+                       (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles);
+  else
+    hipLaunchKernelGGL(k_attention_bf16<4>, dim3((unsigned)blocks), dim3(256), 0, s,
+                       (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }
@@ -358,6 +409,17 @@ int launch_attention_f32(const float* qkv, float* ctx, int B, int T, int H, hipS
 }  // namespace gww
 
 using namespace gww;
+
+#ifdef GWW_STAMP
+extern "C" int gww_debug_stamps_att(unsigned long long* out8, int reset) {
+  GWW_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(gww::g_stamp_att), sizeof(unsigned long long) * 8));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    GWW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gww::g_stamp_att), z, sizeof(z)));
+  }
+  return GWW_OK;
+}
+#endif
 
 extern "C" int gww_attention_bf16(const void* qkv, void* ctx, int B, int T, int n_heads, void* stream) {
   return launch_attention_bf16(qkv, ctx, B, T, n_heads, (hipStream_t)stream);

@@ -67,7 +67,7 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 }  // namespace
 
 // kernel classes of one forward, for the optional per-kernel event trace (bench.py roofline)
-enum : int { TR_MEL = 0, TR_CONV1, TR_CONV2, TR_QKV, TR_ATTN, TR_OUT, TR_FC1, TR_FC2, TR_LN, TR_MLP, TR_COUNT };
+enum : int { TR_MEL = 0, TR_CONV1, TR_CONV2, TR_QKV, TR_ATTN, TR_OUT, TR_FC1, TR_FC2, TR_LN, TR_MLP, TR_MLPQKV, TR_COUNT };
 
 struct TraceSpan { int cls; hipEvent_t a, b; };
 
@@ -223,7 +223,8 @@ extern "C" int gww_encoder_trace_read(gww_encoder* e, float* ms, int* counts) {
 extern "C" int gww_encoder_trace_classes(void) { return TR_COUNT; }
 extern "C" const char* gww_encoder_trace_class_name(int i) {
   static const char* names[TR_COUNT] = {"mel_to_tokens", "conv1_gelu", "conv2_gelu_pos", "ln+qkv_proj", "attention",
-                                        "out_proj", "ln+fc1_gelu", "fc2", "final_layernorm", "mlp_fused(ln+fc1+gelu+fc2)"};
+                                        "out_proj", "ln+fc1_gelu", "fc2", "final_layernorm", "mlp_fused(ln+fc1+gelu+fc2)",
+                                        "mlp_fused+next_ln_qkv"};
   return (i >= 0 && i < TR_COUNT) ? names[i] : "?";
 }
 
@@ -515,8 +516,8 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
       if (mlp_fused && fuse_qkv && i + 1 < e->cfg.n_layers) {
         // ... and the next layer's LN1 + q / k / v projection appended: xn receives x_next (no delta pending)
         const LayerW& Ln = e->layers[i + 1];
-        TR(TR_MLP, launch_mlp_fused(xc, d1, xn, L.u1, L.cb1, L.wmlp, L.b2, nullptr, M, d, F, s, Ln.uqkv, Ln.cbqkv, qkv,
-                                    3 * d));
+        TR(TR_MLPQKV, launch_mlp_fused(xc, d1, xn, L.u1, L.cb1, L.wmlp, L.b2, nullptr, M, d, F, s, Ln.uqkv, Ln.cbqkv, qkv,
+                                       3 * d));
         { float* t = xc; xc = xn; xn = t; }
         pending = nullptr;
         qkv_done = true;
