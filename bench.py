@@ -204,7 +204,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-kernel event trace")
-    ap.add_argument("--split", type=int, default=1, help="1 (default): two half batches on two HIP streams; 0: one stream")
+    ap.add_argument("--split", type=int, default=0, help="0 (default): one stream; 1: two half batches on two HIP streams "
+                    "(paid off before the fused MLP kernel, which owns a whole CU; now within noise)")
     ap.add_argument("--no-train", action="store_true", help="skip the DoRA step timing")
     ap.add_argument("--train-batch", type=int, default=32, help="per-GPU batch of the DoRA step (reference default 32)")
     ap.add_argument("--isolated", action="store_true", help="also time each kernel class in isolation")

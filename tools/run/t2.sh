@@ -1,4 +1,5 @@
 set -o pipefail
-timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_training.py tests/test_gpu_encoder.py -q -m gpu -x -k "attention or training_step or config1 or finite" 2>&1 | tail -4
-for w in 4 8; do echo "waves $w: $(GWW_ATT_WAVES=$w timeout -k 10 300 python tools/bench_kernels.py 2>&1 | grep attention)"; done
-timeout -k 10 600 python tools/stamp_att.py 2>&1 | tail -8
+timeout -k 10 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5
+timeout -k 10 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; python tools/show_bench.py gpurun_out/bench.json
+python -c "
+import json; d=json.load(open('gpurun_out/bench.json')); print(d['roofline']); print(d['config'])"
