@@ -167,7 +167,7 @@ def dora_step(enc_name, per_gpu_batch, dev, world, steps=3, warmup=1):
             total += e[0].elapsed_time(e[4]) / steps
     assert torch.isfinite(loss).all()
     return {"ms": total, "split_ms": times, "per_gpu_batch": per_gpu_batch, "detectors": 2,
-            "trainable_params": int(bucket.numel), "adapter": "DoRA r=8 alpha=32 on q,k,v (12 modules on tiny)",
+            "trainable_params": int(bucket.numel), "adapter": f"DoRA r=8 alpha=32 on q,k,v ({len(targets)} modules on {enc_name})",
             "loss": float(loss.detach())}
 
 

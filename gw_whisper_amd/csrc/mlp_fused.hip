@@ -452,8 +452,25 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     // The tiles already in flight are older than these loads: hipcc's own vmcnt waits retire them first.
     {
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, cshift[4];
+      // the x_new lines of three 64-column chunks are requested together (24 loads per lane; with the 192 output
+      // accumulators still live there is room for no more) -- two exposed round trips instead of six; asm +
+      // hand-counted vmcnt as in the prologue
+      f32x4 xn4[3][2][4];
+      const float* xrow2[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xrow2[i] = x_out + grow[i] * MF_D + 4 * cchunk;
 #pragma unroll
       for (int np = 0; np < MF_KT; ++np) {
+        if (np % 3 == 0) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
+                             : "=v"(xn4[q][h2][i]) : "v"(xrow2[i]), "n"((64 * (np + q) + 32 * h2) * 4) : "memory");
+        }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int t = 2 * np + tt;
@@ -471,14 +488,18 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float* xp = x_out + grow[i] * MF_D + 64 * np + 32 * h2 + 4 * cchunk;
-            f32x4 v = *reinterpret_cast<const f32x4*>(xp);
+            // load k = 8 (np % 3) + 4 h2 + i of the batch: at most the 23 - k younger loads may be outstanding
+            // (the x_next stores are issued only after the whole batch is consumed: the count stays exact
+            // whatever rows are masked)
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xn4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
+            f32x4 v = xn4[np % 3][h2][i];
             const u32x2 dv = *reinterpret_cast<const u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8);
             v[0] += bf2f((unsigned short)(dv[0] & 0xffff));
             v[1] += bf2f((unsigned short)(dv[0] >> 16));
             v[2] += bf2f((unsigned short)(dv[1] & 0xffff));
             v[3] += bf2f((unsigned short)(dv[1] >> 16));
             // rows past M are clamped duplicates of row M - 1: only the real row may update in place
-            if (m_base + 8 * i + crow < M) *reinterpret_cast<f32x4*>(xp) = v;
+            xn4[np % 3][h2][i] = v;      // x_next, stored once the batch is consumed
             if (np == 0 && h2 == 0) {
               float t = (v[0] + v[1]) + (v[2] + v[3]);
               t += __shfl_xor(t, 1, 64);
@@ -497,6 +518,18 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           u32x4 u = *reinterpret_cast<const u32x4*>(slice + r * MF_SLICE_STRIDE + (4 * hh + j) * 16);
           asm volatile("" : "+v"(u)::"memory");
           af[4 * np + j] = __builtin_bit_cast(bf16x8, u);
+        }
+        if (np % 3 == 2) {   // batch consumed: x_next of its three chunks back in place (real rows only: rows past M
+                             // are clamped duplicates of row M - 1 and must not touch it)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (m_base + 8 * i + crow < M)
+                  *reinterpret_cast<f32x4*>(x_out + grow[i] * MF_D + 64 * (np - 2 + q) + 32 * h2 + 4 * cchunk) = xn4[q][h2][i];
+          asm volatile("" ::: "memory");
         }
       }
       float* stat = reinterpret_cast<float*>(slice);
