@@ -37,6 +37,9 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #ifndef GWW_MF_EXP
 #define GWW_MF_EXP 0   // diagnostic builds only: 1 = no DMA in the loop, 2 = no GELU, 4 = no fragment reads in the loop
 #endif
+#ifndef GWW_MF_VG
+#define GWW_MF_VG 18   // VALU instructions scheduled behind each MFMA of a step that carries a GELU piece
+#endif
 #ifndef GWW_MF_AHEAD
 #define GWW_MF_AHEAD 6
 #endif
@@ -390,16 +393,16 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         if (piece >= 0) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
           __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // DS read: fragment + u / cb of the piece
-          __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);  // VALU
+          __builtin_amdgcn_sched_group_barrier(0x002, GWW_MF_VG, 0);  // VALU
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, GWW_MF_VG, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, GWW_MF_VG, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, GWW_MF_VG, 0);
         } else {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -487,7 +490,6 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            float* xp = x_out + grow[i] * MF_D + 64 * np + 32 * h2 + 4 * cchunk;
             // load k = 8 (np % 3) + 4 h2 + i of the batch: at most the 23 - k younger loads may be outstanding
             // (the x_next stores are issued only after the whole batch is consumed: the count stays exact
             // whatever rows are masked)
