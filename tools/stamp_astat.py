@@ -7,9 +7,9 @@ sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "gw_whisper_amd", "csrc")
 so = os.path.join(ROOT, "gpurun_out", "libgww_stamp.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-srcs = ["elementwise.hip", "logmel.hip", "gemm_bf16.hip", "gemm_astat.hip", "gemm_fulln.hip", "gemm_f32.hip", "attention.hip", "encoder.hip"]
+srcs = [f for f in sorted(os.listdir(csrc)) if f.endswith(".hip")]
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast",
-                "-DGWW_STAMP", "-shared", "-o", so] + [os.path.join(csrc, f) for f in srcs], check=True)
+                "-DGWW_STAMP", "-mllvm", "-pragma-unroll-threshold=4000000", "-shared", "-o", so] + [os.path.join(csrc, f) for f in srcs], check=True)
 import torch
 from gw_whisper_amd import _lib
 _lib.LIB_PATH = so
