@@ -35,7 +35,7 @@ constexpr int MF_KT = MF_D / 64;           // 6 k-tiles of fc1
 constexpr int MF_OT = MF_D / 32;           // 12 output sub-tiles of fc2
 constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #ifndef GWW_MF_EXP
-#define GWW_MF_EXP 0   // diagnostic builds only: 1 = no DMA in the loop, 2 = no GELU, 4 = no fragment reads in the loop
+#define GWW_MF_EXP 0   // diagnostic builds only: 1 = no DMA in the loop, 2 = no GELU, 4 = no fragment reads in the loop, 8 = stream folded onto its first 8 tiles
 #endif
 #ifndef GWW_MF_VG
 #define GWW_MF_VG 18   // VALU instructions scheduled behind each MFMA of a step that carries a GELU piece
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr)lds;
   auto issue_piece = [&](int tile, int stage, int j) {
     const unsigned dst = lds_base + (unsigned)(stage * MF_TILE + (MF_GL * wave_u + j) * 1024);
+    if (GWW_MF_EXP & 8) tile &= 7;   // diagnostic: the whole stream collapses onto 128 KB (always L2-hot)
     const unsigned short* src = Wt + ((long)tile * (MF_TILE / 2) + (MF_GL * wave_u + j) * 512);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
