@@ -27,6 +27,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace gww {
 
 namespace {
@@ -46,7 +48,6 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 constexpr int MF_AHEAD = GWW_MF_AHEAD, MF_NST = MF_AHEAD + 1;   // tiles in flight ahead of the one being computed, ring stages
 constexpr int MF_TILE = 128 * 64 * 2;      // 16 KB
 constexpr int MF_GL = 16 / MF_WAVES;       // LDS-DMA pieces per thread per tile
-constexpr int MF_TPC = 12;                 // tiles per ffn chunk: 6 of W1', 6 of W2
 constexpr int MF_FMAX = 1536;              // largest ffn (cb / u staged in LDS)
 constexpr int MF_SLICE_STRIDE = 144, MF_SLICE_BYTES = 32 * MF_SLICE_STRIDE;
 constexpr int MF_OFF_CB = MF_NST * MF_TILE;
@@ -121,7 +122,6 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   const long m_base = (long)blockIdx.x * MF_BM + wave * 32;
   unsigned char* slice = lds + MF_OFF_SLICE + wave * MF_SLICE_BYTES;
   const int crow = lane >> 3, cchunk = lane & 7;
-  const int nch = F / 128;
 
   // ---- ring: the weights arrive pre-tiled (gww_mlp_pack_bf16): tile (c, idx) is 16 contiguous KiB that
   // already hold the swizzled LDS image, in the order the loop consumes them, so the whole weight stream
@@ -313,117 +313,154 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   mf_wait_vmcnt<MF_GL*(MF_AHEAD - 1)>();
   __builtin_amdgcn_s_barrier();
 
-  // Schedule of one ffn chunk (12 tiles, 4 steps of 4 MFMAs each):
-  //   idx 0..2  fc1, n-half 0 (S[0], S[1]), k-thirds 0..2
-  //   idx 3..5  fc1, n-half 1 (S[2], S[3])                  + GELU pieces 0..7  (S[0], S[1] are final)
-  //   idx 6..8  fc2, k-half 0 (P from S[0], S[1]), ng 0..2  + GELU pieces 8..15 (S[2], S[3] are final)
-  //   idx 9..11 fc2, k-half 1 (P from S[2], S[3]), ng 0..2
-  // W fragments are read one step ahead of their use, across tile boundaries too (the ring waits run one
-  // tile ahead, so tile it + 1 is complete and visible while tile it is being computed).  Every step holds
-  // 4 MFMAs, the 4 fragment reads of the next step, one DMA piece and at most one GELU piece, interleaved by
-  // sched_group_barrier so that the VALU work issues in the shadow of the MFMAs.
+  // Software-pipelined schedule over 64-column ffn chunks c' = 0 .. n-1 (n = ffn / 64, even):
+  //   G1(c') : three fc1 tiles [64 n][128 k] -> S[c' & 1]  (two 32-column accumulators)
+  //   G2(c') : three fc2 tiles [128 n2][64 k], O += gelu(S(c')) W2^T, P = pf[c' & 1]
+  //   stream : G1(0) | G1(1) G2(0) | G1(2) G2(1) | ... | G1(n-1) G2(n-2) | G2(n-1)
+  // The GELU of chunk c' (16 values per lane = 4 pieces) is split: its first half rides under G2(c' - 1), its
+  // second half under G1(c' + 1) -- every tile carries 1.33 values per step (about 5 VALU instructions per MFMA
+  // gap, which is what one wave per SIMD can hide) instead of half the tiles carrying twice that.  S and P are
+  // double buffered by the chunk parity: no more registers than the 128-column schedule needed.
+  // W fragments are read one step ahead of their use, across tile boundaries too (the ring waits run one tile
+  // ahead, so tile it + 1 is complete and visible while tile it is being computed).
   bf16x8 wf[2][4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
     wf[0][t] = *reinterpret_cast<const bf16x8*>(lds + (t & 1) * 8192 + off1[t >> 1]);
 
-  // fragment u of step (idx, sub) inside its tile: byte offset
-  auto frag_off = [&](int idx, int sub, int u) -> int {
-    if (idx < MF_KT) return (u & 1) * 8192 + off1[2 * sub + (u >> 1)];   // (tl = u & 1, k-step 2 sub + (u >> 1))
-    return u * 4096 + off2[sub];
+  const int nck = F / 64;                                             // 64-column chunks
+  const int total = 6 * nck + (QKV ? (NQ / 128) * MF_KT : 0);         // tiles in the weight stream
+  int stage = 0;   // ring stage of the tile being computed
+  int it = 0;      // flat index of the tile being computed
+
+  // fragment u of the FIRST step of a tile of the given kind (0 fc1, 1 fc2, 2 q/k/v): byte offset in the tile
+  auto first_off = [&](int kind, int u) -> int {
+    return kind == 0 ? (u & 1) * 8192 + off1[u >> 1] : (kind == 1 ? u * 4096 + off2[0] : u * 4096 + offq[0]);
   };
 
-  const int total = nch * MF_TPC + (QKV ? (NQ / 128) * MF_KT : 0);   // tiles in the weight stream
-  int stage = 0;   // ring stage of the tile being computed
-  for (int c = 0; c < nch; ++c) {
+  // One tile = 4 steps of 4 MFMAs.  KIND 0: fc1 tile kt3 of the chunk whose accumulators are S[2 PAR + tl];
+  // KIND 1: fc2 tile ng with P = pf[2 PAR + ..].  ride_t >= 0: S index whose GELU values ride in this tile
+  // (values v0 .. of its four pieces, 16 per S index, spread 1-1-2 over the 12 steps of a phase);
+  // next_kind: kind of the tile that follows (its first fragments are prefetched in the last step).
+  auto run_tile = [&](auto kind_c, auto par_c, auto idx3_c, int cpair, auto ride_t_c, int ride_cpair, int next_kind) {
+    constexpr int KIND = decltype(kind_c)::value, PAR = decltype(par_c)::value, IDX3 = decltype(idx3_c)::value;
+    constexpr int RIDE_T = decltype(ride_t_c)::value;
+    (void)cpair;
+    mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
+    __builtin_amdgcn_s_barrier();
+    MSTAMP(1);
+    const int dma_tile = it + MF_AHEAD < total ? it + MF_AHEAD : total - 1;
+    const int dma_stage = stage + MF_AHEAD >= MF_NST ? stage + MF_AHEAD - MF_NST : stage + MF_AHEAD;
+    const int stage_next = stage + 1 == MF_NST ? 0 : stage + 1;
+    MSTAMP(2);
 #pragma unroll
-    for (int idx = 0; idx < MF_TPC; ++idx) {
-      // tile it = 12 c + idx.  Wait for tile it + 1; the barrier also says every wave is done with tile
-      // it - 1, whose stage receives tile it + MF_AHEAD (past the end: a harmless re-read of the last tile,
-      // so that the counted wait is the same in every iteration).
-      mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
-      __builtin_amdgcn_s_barrier();
-      MSTAMP(1);
-      const int it = c * MF_TPC + idx;
-      const int dma_tile = it + MF_AHEAD < total ? it + MF_AHEAD : total - 1;
-      const int dma_stage = stage + MF_AHEAD >= MF_NST ? stage + MF_AHEAD - MF_NST : stage + MF_AHEAD;
-      const int stage_next = stage + 1 == MF_NST ? 0 : stage + 1;
-      MSTAMP(2);
+    for (int sub = 0; sub < 4; ++sub) {
+      bf16x8(&cur)[4] = wf[sub & 1];          // every tile has 4 steps: the parity is static
+      bf16x8(&nxt)[4] = wf[(sub + 1) & 1];
+      const unsigned char* Wn = lds + (sub == 3 ? stage_next : stage) * MF_TILE;
+      // GELU values of this step: step j = 4 IDX3 + sub of the phase takes values [16 j / 12, 16 (j + 1) / 12)
+      const int j12 = 4 * IDX3 + sub;
+      const int v0 = (16 * j12) / 12, v1 = (16 * (j12 + 1)) / 12;
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(GWW_MF_EXP & 1)) issue_piece(dma_tile, dma_stage, sub);
+      if (RIDE_T >= 0) {
 #pragma unroll
-      for (int sub = 0; sub < 4; ++sub) {
-        const int q = 4 * idx + sub;
-        bf16x8(&cur)[4] = wf[q & 1];
-        bf16x8(&nxt)[4] = wf[(q + 1) & 1];
-        const int nidx = sub == 3 ? (idx + 1 == MF_TPC ? 0 : idx + 1) : idx;
-        const int nsub = (sub + 1) & 3;
-        const unsigned char* Wn = lds + (sub == 3 ? stage_next : stage) * MF_TILE;
-        const bool to_qkv = QKV && c == nch - 1 && idx == MF_TPC - 1 && sub == 3;   // next step = first QKV step
-        // GELU piece riding in this step: two steps out of three in tiles 3..8
-        int piece = -1;
-        if (idx >= 3 && idx < 9) {
-          const int qq = 4 * (idx - 3) + sub;          // 0 .. 23
-          if (qq % 3 != 2) piece = qq - qq / 3;         // 0 .. 15
+        for (int v = v0; v < v1; ++v) {
+          const int p = 4 * RIDE_T + (v >> 2), e = v & 3;
+          if (e == 0) act_begin(0, ride_cpair, p);
+          act_val(0, p, e);
+          if (e == 3) act_end(0, p);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(GWW_MF_EXP & 1)) issue_piece(dma_tile, dma_stage, sub);
-        if (piece >= 0) act_piece(0, c, piece);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (idx < MF_KT) {
-            // ---- fc1: S[2 nh + tl] (+)= W1' tile rows 32 tl .. . a[k-step]
-            const int nh = idx / 3, kt3 = idx - 3 * nh, tl = u & 1;
-            const int ks = 2 * sub + (u >> 1);                      // k-step of the tile, 0 .. 7
-            const int afi = 4 * (2 * kt3 + (ks >> 2)) + (ks & 3);   // af[4 S + j]
-            if (kt3 == 0 && ks == 0) {
-              f32x16 z;
-#pragma unroll
-              for (int j = 0; j < 16; ++j) z[j] = 0.f;
-              sacc[2 * nh + tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[u], af[afi], z, 0, 0, 0);
-            } else {
-              sacc[2 * nh + tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[u], af[afi], sacc[2 * nh + tl], 0, 0, 0);
-            }
-          } else {
-            // ---- fc2: O[4 ng + u] += W2 tile (rows 32 u ..) . P[k-step]
-            const int i2 = idx - MF_KT, kh = i2 / 3, ng = i2 - 3 * kh;
-            oacc[4 * ng + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                cur[u], __builtin_bit_cast(bf16x8, pf[2 * kh + (sub >> 1)][sub & 1]), oacc[4 * ng + u], 0, 0, 0);
-          }
-          if (!(GWW_MF_EXP & 4)) nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + (to_qkv ? u * 4096 + offq[0] : frag_off(nidx, nsub, u)));
-        }
-        // pipeline of the step: MFMA, fragment read, a slice of the VALU work -- four times
-        if (piece >= 0) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // DS read: fragment + u / cb of the piece
-          __builtin_amdgcn_sched_group_barrier(0x002, GWW_MF_VG, 0);  // VALU
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, GWW_MF_VG, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, GWW_MF_VG, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, GWW_MF_VG, 0);
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
       }
-      stage = stage_next;
-      MSTAMP(8 + idx);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (KIND == 0) {
+          // ---- fc1: S[2 PAR + tl] (+)= W1' tile rows 32 tl .. . a[k-step]
+          const int tl = u & 1;
+          const int ks = 2 * sub + (u >> 1);                       // k-step of the tile, 0 .. 7
+          const int afi = 4 * (2 * IDX3 + (ks >> 2)) + (ks & 3);   // af[4 S + j]
+          if (IDX3 == 0 && ks == 0) {
+            f32x16 z;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) z[j] = 0.f;
+            sacc[2 * PAR + tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[u], af[afi], z, 0, 0, 0);
+          } else {
+            sacc[2 * PAR + tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[u], af[afi], sacc[2 * PAR + tl], 0, 0, 0);
+          }
+        } else {
+          // ---- fc2: O[4 ng + u] += W2 tile (rows 32 u ..) . P[k-step];  ng = IDX3
+          oacc[4 * IDX3 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              cur[u], __builtin_bit_cast(bf16x8, pf[2 * PAR + (sub >> 1)][sub & 1]), oacc[4 * IDX3 + u], 0, 0, 0);
+        }
+        if (!(GWW_MF_EXP & 4)) {
+          int off;
+          if (sub == 3) off = first_off(next_kind, u);
+          else off = KIND == 0 ? (u & 1) * 8192 + off1[2 * (sub + 1) + (u >> 1)] : u * 4096 + off2[sub + 1];
+          nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + off);
+        }
+      }
+      // pipeline of the step: MFMA, fragment read, a slice of the VALU work -- four times
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    stage = stage_next;
+    ++it;
+    MSTAMP(8 + (KIND == 0 ? IDX3 : 3 + IDX3) + 6 * PAR);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using IM = std::integral_constant<int, -1>;
+
+  // G1(0): no GELU to carry yet; its first half is then computed in the open (once per 128 rows)
+  run_tile(I0{}, I0{}, I0{}, 0, IM{}, 0, 0);
+  run_tile(I0{}, I0{}, I1{}, 0, IM{}, 0, 0);
+  run_tile(I0{}, I0{}, I2{}, 0, IM{}, 0, 0);
+  act_piece(0, 0, 0); act_piece(0, 0, 1); act_piece(0, 0, 2); act_piece(0, 0, 3);
+  int b = 0;
+  for (; b + 2 < nck; b += 2) {
+    // ---- block b (parity 0): G1(b + 1) -> S[2..3] carrying the second half of GELU(b) (S[1]);
+    //      G2(b) with pf[0..1] carrying the first half of GELU(b + 1) (S[2])
+    run_tile(I0{}, I1{}, I0{}, 0, I1{}, b >> 1, 0);
+    run_tile(I0{}, I1{}, I1{}, 0, I1{}, b >> 1, 0);
+    run_tile(I0{}, I1{}, I2{}, 0, I1{}, b >> 1, 1);
+    run_tile(I1{}, I0{}, I0{}, 0, I2{}, b >> 1, 1);
+    run_tile(I1{}, I0{}, I1{}, 0, I2{}, b >> 1, 1);
+    run_tile(I1{}, I0{}, I2{}, 0, I2{}, b >> 1, 0);
+    // ---- block b + 1 (parity 1): G1(b + 2) -> S[0..1] carrying the second half of GELU(b + 1) (S[3]);
+    //      G2(b + 1) with pf[2..3] carrying the first half of GELU(b + 2) (S[0])
+    run_tile(I0{}, I0{}, I0{}, 0, I3{}, b >> 1, 0);
+    run_tile(I0{}, I0{}, I1{}, 0, I3{}, b >> 1, 0);
+    run_tile(I0{}, I0{}, I2{}, 0, I3{}, b >> 1, 1);
+    run_tile(I1{}, I1{}, I0{}, 0, I0{}, (b >> 1) + 1, 1);
+    run_tile(I1{}, I1{}, I1{}, 0, I0{}, (b >> 1) + 1, 1);
+    run_tile(I1{}, I1{}, I2{}, 0, I0{}, (b >> 1) + 1, 0);
   }
+  // ---- last pair (b = n - 2): G1(n - 1) + second half of GELU(n - 2); G2(n - 2) + first half of GELU(n - 1);
+  //      then the second half of GELU(n - 1) in the open (nothing left to hide it under) and G2(n - 1)
+  run_tile(I0{}, I1{}, I0{}, 0, I1{}, b >> 1, 0);
+  run_tile(I0{}, I1{}, I1{}, 0, I1{}, b >> 1, 0);
+  run_tile(I0{}, I1{}, I2{}, 0, I1{}, b >> 1, 1);
+  run_tile(I1{}, I0{}, I0{}, 0, I2{}, b >> 1, 1);
+  run_tile(I1{}, I0{}, I1{}, 0, I2{}, b >> 1, 1);
+  run_tile(I1{}, I0{}, I2{}, 0, I2{}, b >> 1, 1);
+  act_piece(0, b >> 1, 12); act_piece(0, b >> 1, 13); act_piece(0, b >> 1, 14); act_piece(0, b >> 1, 15);
+  run_tile(I1{}, I1{}, I0{}, 0, IM{}, 0, 1);
+  run_tile(I1{}, I1{}, I1{}, 0, IM{}, 0, 1);
+  run_tile(I1{}, I1{}, I2{}, 0, IM{}, 0, QKV ? 2 : 1);
+
   if constexpr (!QKV) {
     mf_wait_vmcnt<0>();   // the re-reads issued past the end
     // ---- epilogue: + b2 -> bf16 -> wave-private LDS transpose -> whole-line stores
@@ -459,7 +496,10 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       // the x_new lines of three 64-column chunks are requested together (24 loads per lane; with the 192 output
       // accumulators still live there is room for no more) -- two exposed round trips instead of six; asm +
       // hand-counted vmcnt as in the prologue
-      f32x4 xn4[3][2][4];
+      // (second batch parked in accumulator registers: by then the operand fragments fill the arch VGPRs and
+      //  hipcc would otherwise copy the just-requested registers away BEFORE the data has landed; half of the output
+      //  accumulators are free at that point)
+      f32x4 xn4[3][2][4], xa4[3][2][4];
       const float* xrow2[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) xrow2[i] = x_out + grow[i] * MF_D + 4 * cchunk;
@@ -471,9 +511,14 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-              for (int i = 0; i < 4; ++i)
-                asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
-                             : "=v"(xn4[q][h2][i]) : "v"(xrow2[i]), "n"((64 * (np + q) + 32 * h2) * 4) : "memory");
+              for (int i = 0; i < 4; ++i) {
+                if (np == 0)
+                  asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
+                               : "=v"(xn4[q][h2][i]) : "v"(xrow2[i]), "n"((64 * (np + q) + 32 * h2) * 4) : "memory");
+                else
+                  asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
+                               : "=a"(xa4[q][h2][i]) : "v"(xrow2[i]), "n"((64 * (np + q) + 32 * h2) * 4) : "memory");
+              }
         }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -494,8 +539,14 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
             // load k = 8 (np % 3) + 4 h2 + i of the batch: at most the 23 - k younger loads may be outstanding
             // (the x_next stores are issued only after the whole batch is consumed: the count stays exact
             // whatever rows are masked)
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xn4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
-            f32x4 v = xn4[np % 3][h2][i];
+            f32x4 v;
+            if (np < 3) {
+              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xn4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
+              v = xn4[np % 3][h2][i];
+            } else {
+              asm volatile("s_waitcnt vmcnt(%1)" : "+a"(xa4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
+              v = xa4[np % 3][h2][i];
+            }
             const u32x2 dv = *reinterpret_cast<const u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8);
             v[0] += bf2f((unsigned short)(dv[0] & 0xffff));
             v[1] += bf2f((unsigned short)(dv[0] >> 16));
@@ -563,7 +614,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     __builtin_amdgcn_s_barrier();     // ... and everybody else's; u / cb visible
 
     // ---- second GEMM: qkv[32 rows, NQ] = LN1(x_next) Wqkv'^T, n-tiles of 128 columns, 6 k-tiles each
-    const int T0 = nch * MF_TPC;
+    const int T0 = 6 * nck;
     f32x16 acc[4];
     for (int nt = 0; nt < NQ / 128; ++nt) {
 #pragma unroll
@@ -573,8 +624,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         if (nt > 0 && kt != MF_KT - 1) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + 8>();
         else mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
         __builtin_amdgcn_s_barrier();
-        const int it = T0 + nt * MF_KT + kt;
-        const int dma_tile = it + MF_AHEAD < total ? it + MF_AHEAD : total - 1;
+        const int itq = T0 + nt * MF_KT + kt;
+        const int dma_tile = itq + MF_AHEAD < total ? itq + MF_AHEAD : total - 1;
         const int dma_stage = stage + MF_AHEAD >= MF_NST ? stage + MF_AHEAD - MF_NST : stage + MF_AHEAD;
         const int stage_next = stage + 1 == MF_NST ? 0 : stage + 1;
 #pragma unroll
@@ -659,32 +710,41 @@ __global__ __launch_bounds__(256) void k_mlp_pack(const unsigned short* __restri
                                                   const unsigned short* __restrict__ w2,
                                                   const unsigned short* __restrict__ wq,
                                                   unsigned short* __restrict__ out, int F, long n_chunks16) {
-  const int mlp_tiles = (F / 128) * MF_TPC;
+  const int nck = F / 64, mlp_tiles = 6 * nck;
   for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < n_chunks16; g += (long)gridDim.x * 256) {
     const int tile = (int)(g >> 10), within = (int)(g & 1023);
     const int row = within >> 3, chunk = (within & 7) ^ ((row >> 1) & 7);
-    const int c = tile / MF_TPC, idx = tile - c * MF_TPC;
     u32x4 v;
     if (tile >= mlp_tiles) {
       // appended LN1-folded q / k / v panel [NQ, 384]: n-tile major, 6 k-tiles each, [128 n][64 k] images
       const int it2 = tile - mlp_tiles, nt = it2 / MF_KT, kt = it2 - nt * MF_KT;
       v = *reinterpret_cast<const u32x4*>(wq + (long)(128 * nt + row) * MF_D + 64 * kt + 8 * chunk);
-    } else if (idx < MF_KT) {
-      // [64 n][128 k] image: 16 chunks per row, chunk ch stored at ch ^ (row & 15)
-      const int row2 = within >> 4, ch = (within & 15) ^ (row2 & 15);
-      const int nh = idx / 3, kt3 = idx - 3 * nh;
-      v = *reinterpret_cast<const u32x4*>(w1 + (long)(128 * c + 64 * nh + row2) * MF_D + 128 * kt3 + 8 * ch);
     } else {
-      const int i2 = idx - MF_KT, kh = i2 / 3, ng = i2 - 3 * kh;
-      const unsigned short* src = w2 + (long)(128 * ng + row) * F + 128 * c + 64 * kh;
-      unsigned short e[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int p = 8 * chunk + j;
-        e[j] = src[(p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1)];
+      // stream order of k_mlp_fused:  G1(0) | G1(1) G2(0) | G1(2) G2(1) | ... | G1(n-1) G2(n-2) | G2(n-1)
+      int kind, cp, idx3;
+      if (tile < 3) { kind = 0; cp = 0; idx3 = tile; }
+      else {
+        const int k = tile - 3, blk = k / 6, w = k - 6 * blk;
+        if (blk == nck - 1) { kind = 1; cp = blk; idx3 = w; }
+        else if (w < 3) { kind = 0; cp = blk + 1; idx3 = w; }
+        else { kind = 1; cp = blk; idx3 = w - 3; }
       }
-      v = u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
-                (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+      if (kind == 0) {
+        // fc1 tile [64 n][128 k]: 16 chunks per row, chunk ch stored at ch ^ (row & 15); k-third idx3
+        const int row2 = within >> 4, ch = (within & 15) ^ (row2 & 15);
+        v = *reinterpret_cast<const u32x4*>(w1 + (long)(64 * cp + row2) * MF_D + 128 * idx3 + 8 * ch);
+      } else {
+        // fc2 tile [128 n2][64 k]: n-group idx3, k = the 64 ffn columns of chunk cp, bits 2 / 3 of k swapped
+        const unsigned short* src = w2 + (long)(128 * idx3 + row) * F + 64 * cp;
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int p = 8 * chunk + j;
+          e[j] = src[(p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1)];
+        }
+        v = u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                  (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+      }
     }
     reinterpret_cast<u32x4*>(out)[g] = v;
   }

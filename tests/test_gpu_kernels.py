@@ -304,30 +304,35 @@ def test_dora_merge(T, gww, d_out, d_in, r):
 
 
 def test_mlp_pack_layout(T, gww):
-    """Tile stream of the fused MLP: fc1 tiles are swizzled [64 n][128 k] images; fc2 tiles [128 n][64 k]
-    carry k with bits 2 / 3 swapped inside every 16-group."""
+    """Tile stream of the fused MLP, in the order the kernel consumes it over 64-column ffn chunks c':
+    G1(0) | G1(1) G2(0) | G1(2) G2(1) | ... | G1(n-1) G2(n-2) | G2(n-1); fc1 tiles are swizzled [64 n][128 k] images,
+    fc2 tiles [128 n][64 k] carry k with bits 2 / 3 swapped inside every 16-group."""
     from gw_whisper_amd import ops
     F, d = 256, 384
     w1 = T.arange(F * d, dtype=T.float32).reshape(F, d).remainder(251).cuda().bfloat16()
     w2 = (T.arange(d * F, dtype=T.float32).reshape(d, F).remainder(241) + 0.5).cuda().bfloat16()
-    out = ops.mlp_pack(w1, w2).float().cpu().numpy().reshape(F // 128, 12, 8192)
+    n = F // 64
+    out = ops.mlp_pack(w1, w2).float().cpu().numpy().reshape(6 * n, 8192)
     w1n, w2n = w1.float().cpu().numpy(), w2.float().cpu().numpy()
     k = np.arange(64)
     sw = (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)
-    for c in range(F // 128):
-        for idx in range(12):
-            if idx < 6:      # fc1: [64 n][128 k], chunk ^ (row & 15)
-                img = out[c, idx].reshape(64, 16, 8)
-                nh, kt3 = divmod(idx, 3)
-                for row in (0, 1, 17, 63):
-                    logical = np.stack([img[row, ch ^ (row & 15)] for ch in range(16)]).reshape(128)
-                    np.testing.assert_array_equal(logical, w1n[128 * c + 64 * nh + row, 128 * kt3:128 * kt3 + 128])
-            else:            # fc2: [128 n2][64 k], chunk ^ ((row >> 1) & 7), k with bits 2 / 3 swapped
-                img = out[c, idx].reshape(128, 8, 8)
-                kh, ng = divmod(idx - 6, 3)
-                for row in (0, 1, 2, 77, 127):
-                    logical = np.stack([img[row, ch ^ ((row >> 1) & 7)] for ch in range(8)]).reshape(64)
-                    np.testing.assert_array_equal(logical, w2n[128 * ng + row, 128 * c + 64 * kh:128 * c + 64 * kh + 64][sw])
+    order = [("g1", 0, i) for i in range(3)]
+    for blk in range(n):
+        if blk + 1 < n:
+            order += [("g1", blk + 1, i) for i in range(3)]
+        order += [("g2", blk, i) for i in range(3)]
+    assert len(order) == 6 * n
+    for tile, (kind, cp, idx3) in enumerate(order):
+        if kind == "g1":     # fc1: [64 n][128 k], chunk ^ (row & 15); rows 64 cp .., k-third idx3
+            img = out[tile].reshape(64, 16, 8)
+            for row in (0, 1, 17, 63):
+                logical = np.stack([img[row, ch ^ (row & 15)] for ch in range(16)]).reshape(128)
+                np.testing.assert_array_equal(logical, w1n[64 * cp + row, 128 * idx3:128 * idx3 + 128])
+        else:                # fc2: [128 n2][64 k], chunk ^ ((row >> 1) & 7); n-group idx3, k = ffn columns of chunk cp
+            img = out[tile].reshape(128, 8, 8)
+            for row in (0, 1, 2, 77, 127):
+                logical = np.stack([img[row, ch ^ ((row >> 1) & 7)] for ch in range(8)]).reshape(64)
+                np.testing.assert_array_equal(logical, w2n[128 * idx3 + row, 64 * cp:64 * cp + 64][sw])
 
 
 @pytest.mark.parametrize("M,F", [(128, 128), (1500, 1536), (777, 512), (4000, 1536), (70000, 1536)])
