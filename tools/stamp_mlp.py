@@ -26,7 +26,7 @@ w2 = (torch.randn(d, ffn, device=dev) / ffn ** 0.5).bfloat16(); b2 = torch.randn
 w1_f, u1, c1 = ops.ln_fold_weights(w1.float(), lw, lb, b1)
 wt = ops.mlp_pack(w1_f, w2)
 fn = lambda: ops.mlp_fused(x, dl, wt, u1, c1, b2)
-names = ["prologue", "ring wait + barrier", "stage bookkeeping", "epilogue"] + ["-"] * 4 + [f"tile idx {i} ({'fc1' if i < 6 else 'fc2'})" for i in range(12)]
+names = ["prologue", "ring wait + barrier", "stage bookkeeping", "epilogue"] + ["-"] * 4 + [f"parity {i // 6} {'fc1' if i % 6 < 3 else 'fc2'} tile {i % 3}" for i in range(12)]
 fn(); torch.cuda.synchronize()
 buf = (C.c_ulonglong * 24)()
 lib.gww_debug_stamps_mlp(buf, 1)
