@@ -796,6 +796,8 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
                                 W.bqkv + off, t.proj == 0 ? 0.125f : 1.0f, t.scaling, t.A, t.B, t.mag, t.nrm, t.dA,
                                 t.dB, t.dm, M, d, t.r, s));
     }
+    // below layer 0 the gradient only continues into the conv stem: skip it when nobody asked for d_x0 / d_mel
+    if (l == 0 && !d_x0 && !d_mel) break;
     GWW_TRY(gemm_dx(dqkv, 3L * d, W.wqkvT, dh, d, 3 * d));
     GWW_TRY(launch_ln_bwd(x_in(l), W.ln1w, dh, 0, dx, 1, dxb, M, d, s));
   }
