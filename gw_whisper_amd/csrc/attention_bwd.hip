@@ -50,9 +50,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int row0, i
 }  // namespace
 
 // D[b, h, t] = sum_d dO[b, t, h*64 + d] * O[b, t, h*64 + d]
+// nz[(b H + h) * n64 + t / 64] |= 1 when row t of dO (head h) is not all zero: the dQ / dK,dV kernels skip the
+// query tiles whose dO is zero -- the classifier heads pool ONE token (Signal_vs_Noise/src/model.py:25-26), so
+// in the last layer 23 of the 24 query tiles carry no gradient at all.
 __global__ __launch_bounds__(256) void k_attn_rowdot(const unsigned short* __restrict__ o,
                                                      const unsigned short* __restrict__ d_o,
-                                                     float* __restrict__ D, int T, int H, long rows) {
+                                                     float* __restrict__ D, unsigned int* __restrict__ nz, int T,
+                                                     int H, long rows) {
   // one 8-lane group per (row, head): 8 lanes x 8 bf16 = 64
   const long g = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
   const int sub = threadIdx.x & 7;
@@ -71,10 +75,15 @@ __global__ __launch_bounds__(256) void k_attn_rowdot(const unsigned short* __res
   s += __shfl_xor(s, 1, 64);
   s += __shfl_xor(s, 2, 64);
   s += __shfl_xor(s, 4, 64);
+  unsigned int any = ((b[0] | b[1] | b[2] | b[3]) & 0x7fff7fffu) != 0u;   // +-0 count as zero
+  any |= __shfl_xor(any, 1, 64);
+  any |= __shfl_xor(any, 2, 64);
+  any |= __shfl_xor(any, 4, 64);
   if (sub == 0) {
     const long bidx = row / T;
     const int t = (int)(row - bidx * T);
     D[(bidx * H + h) * T + t] = s;
+    if (any) atomicOr(nz + (bidx * H + h) * ((T + KB - 1) / KB) + t / KB, 1u);
   }
 }
 
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const unsigned short* __
                                                         const float* __restrict__ lse,
                                                         const float* __restrict__ Dv,
                                                         unsigned short* __restrict__ dqkv, int T, int H,
-                                                        int q_tiles) {
+                                                        int q_tiles, const unsigned int* __restrict__ nz) {
   // per stage: K row image, K transposed-read image, V row image
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 3 * TILE_BYTES];   // 48 KB
   auto Kr = [&](int buf) -> unsigned char* { return lds + (buf * 3 + 0) * TILE_BYTES; };
@@ -102,6 +111,19 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const unsigned short* __
   const int r = lane & 31, hh = lane >> 5;
   const int q_row = qt * TB + wave * 32 + r;
   const int q_ld = q_row < T ? q_row : T - 1;
+  {   // dO of these 128 queries all zero (wave-uniform: the flags are per block): dQ = 0, nothing to stream
+    const int n64 = (T + KB - 1) / KB;
+    const unsigned int* f = nz + (long)bh * n64;
+    const unsigned int live = f[2 * qt] | (2 * qt + 1 < n64 ? f[2 * qt + 1] : 0u);
+    if (!live) {
+      if (q_row < T) {
+        unsigned short* orow = dqkv + ((long)b * T + q_row) * rs + h * DH;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *reinterpret_cast<u32x2*>(orow + 8 * c + 4 * hh) = u32x2{0u, 0u};
+      }
+      return;
+    }
+  }
 
   bf16x8 qf[4], dof[4];
 #pragma unroll
@@ -199,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
                                                          const float* __restrict__ lse,
                                                          const float* __restrict__ Dv,
                                                          unsigned short* __restrict__ dqkv, int T, int H,
-                                                         int k_tiles) {
+                                                         int k_tiles, const unsigned int* __restrict__ nz) {
   // per stage: Q row image, Q transposed-read image, dO row image, dO transposed-read image, lse[64], D[64]
   constexpr int STAGE = 4 * TILE_BYTES + 512;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];   // 65 KB
@@ -271,13 +293,22 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
 #pragma unroll
     for (int j = 0; j < 16; ++j) { dkt[n][j] = 0.f; dvt[n][j] = 0.f; }
 
+  // only the query tiles whose dO is not all zero contribute (dV += P^T dO, dS = P (dO V^T - D) with D = 0 there)
   const int n_qt = (T + KB - 1) / KB;
-  gload(0);
-  lstore(0);
+  const unsigned int* live = nz + (long)bh * n_qt;
+  auto next_live = [&](int q) {
+    while (q < n_qt && !live[q]) ++q;
+    return q;
+  };
+  int qt = next_live(0), buf = 0;
+  if (qt < n_qt) {
+    gload(qt);
+    lstore(0);
+  }
   __syncthreads();
-  for (int qt = 0; qt < n_qt; ++qt) {
-    const int buf = qt & 1;
-    if (qt + 1 < n_qt) gload(qt + 1);
+  while (qt < n_qt) {
+    const int qn = next_live(qt + 1);
+    if (qn < n_qt) gload(qn);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       // S[q][key], dP[q][key]: rows q = 32 g + (reg&3) + 8 (reg>>2) + 4 hh in registers, key on the lane
@@ -314,8 +345,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
         }
       }
     }
-    if (qt + 1 < n_qt) lstore(buf ^ 1);
+    if (qn < n_qt) lstore(buf ^ 1);
     __syncthreads();
+    qt = qn;
+    buf ^= 1;
   }
   if (key_row < T) {
     unsigned short* krow = dqkv + ((long)b * T + key_row) * rs + d + h * DH;
@@ -332,24 +365,27 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
   }
 }
 
-// qkv, ctx, dctx bf16; lse [B,H,T] from the forward; D [B,H,T] scratch; dqkv [B,T,3d] out
+// qkv, ctx, dctx bf16; lse [B,H,T] from the forward; D scratch of B H (T + ceil(T / 64)) floats (row dots, then
+// the live-tile flags); dqkv [B,T,3d] out
 int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* D,
                               void* dqkv, int B, int T, int H, hipStream_t s) {
   GWW_REQUIRE(qkv && ctx && dctx && lse && D && dqkv, "attention_bwd: NULL operand");
   GWW_REQUIRE(B >= 0 && T > 0 && H > 0, "attention_bwd: bad shape");
   if (B == 0) return GWW_OK;
   const long rows = (long)B * T;
+  unsigned int* nz = reinterpret_cast<unsigned int*>(D + rows * H);   // [B, H, ceil(T / 64)] live-tile flags
+  GWW_HIP(hipMemsetAsync(nz, 0, sizeof(unsigned int) * B * H * cdiv(T, KB), s));
   hipLaunchKernelGGL(k_attn_rowdot, dim3((unsigned)cdiv(rows * H * 8, 256)), dim3(256), 0, s,
-                     (const unsigned short*)ctx, (const unsigned short*)dctx, D, T, H, rows);
+                     (const unsigned short*)ctx, (const unsigned short*)dctx, D, nz, T, H, rows);
   GWW_LAUNCH_CHECK();
   const int tiles = (T + TB - 1) / TB;
   const long blocks = (long)tiles * B * H;
   GWW_REQUIRE(blocks < 2147483647L, "attention_bwd: grid too large");
   hipLaunchKernelGGL(k_attn_bwd_dq, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)qkv,
-                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles);
+                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles, nz);
   GWW_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_attn_bwd_dkv, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)qkv,
-                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles);
+                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles, nz);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }

@@ -641,7 +641,7 @@ TrainWs train_ws(const gww_enc_cfg& c, int B) {
   w.dh = take(Mp * d * 2);
   w.dctx = take(Mp * d * 2);
   w.dqkv = take(Mp * 3 * d * 2);
-  w.Dv = take((size_t)B * H * T * 4);
+  w.Dv = take((size_t)B * H * (T + (T + 63) / 64) * 4);   // row dots + live-tile flags
   w.z1 = take(((size_t)B * (Tin + 2) + 256) * d * 2);            // stem backward: conv1 pre-activation / its gradient
   w.col1 = take(((size_t)B * (Tin + 2) + 256) * kConv1Kpad * 2); // stem backward: conv1 taps side by side
   w.total = off;

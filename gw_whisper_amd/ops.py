@@ -260,7 +260,7 @@ def attention_bwd(qkv, ctx, dctx, lse, n_heads: int) -> torch.Tensor:
     lse = _dev(lse, torch.float32, "lse")
     B, T, d3 = qkv.shape
     dqkv = torch.empty_like(qkv)
-    scratch = torch.empty_like(lse)
+    scratch = torch.empty(B * n_heads * (T + (T + 63) // 64), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
         check(lib().gww_attention_bwd_bf16(qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(),
                                            scratch.data_ptr(), dqkv.data_ptr(), B, T, n_heads, _stream()),

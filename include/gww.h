@@ -261,7 +261,8 @@ int gww_gemm_f32(const float* A, const float* W, const float* bias, const float*
 int gww_attention_bf16(const void* qkv, void* ctx, int B, int T, int n_heads, void* stream);
 int gww_attention_f32(const float* qkv, float* ctx, int B, int T, int n_heads, void* stream);
 /* attention backward: dqkv [B,T,3d] from qkv, ctx (forward output), dctx and the forward's lse [B,H,T]
- * (gww_attention_lse_bf16 below); d_scratch [B,H,T] fp32 */
+ * (gww_attention_lse_bf16 below); d_scratch: B * H * (T + ceil(T / 64)) fp32 words (row dots + live-tile flags:
+ * query tiles whose dctx rows are all zero are skipped, which is most of them under last-token pooling) */
 int gww_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse,
                            float* d_scratch, void* dqkv, int B, int T, int n_heads, void* stream);
 /* forward attention that also returns the row log-sum-exp lse [B,H,T] */

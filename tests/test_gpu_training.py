@@ -70,6 +70,36 @@ def test_attention_backward(T, gww, B, Tn, H):
     assert np.sqrt(((dqkv - dqkv_ref) ** 2).mean()) < 3e-3 * scale
 
 
+@pytest.mark.parametrize("B,Tn,H,live", [(2, 1500, 2, "last"), (1, 333, 1, "middle"), (1, 200, 2, "none"),
+                                          (2, 1500, 1, "one_head")])
+def test_attention_backward_sparse_dctx(T, gww, B, Tn, H, live):
+    """Query tiles whose dctx rows are all zero are skipped (last-token pooling, Signal_vs_Noise/src/model.py:25-26):
+    the result must equal the dense formula, including exact zeros where no gradient flows."""
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(Tn + H)
+    qkv = _bf(rng.standard_normal((B, Tn, 3 * H * 64)) * 0.6)
+    dctx = np.zeros((B, Tn, H * 64), np.float32)
+    if live == "last":
+        dctx[:, -1] = _bf(rng.standard_normal((B, H * 64)))
+    elif live == "middle":
+        dctx[:, 130:140] = _bf(rng.standard_normal((B, 10, H * 64)))
+    elif live == "one_head":
+        dctx[1, 700:703, :64] = _bf(rng.standard_normal((3, 64)))
+        dctx[0, 5, :64] = -0.0
+    ctx_ref, lse_ref, dqkv_ref = _attn_grads(qkv.astype(np.float64), dctx.astype(np.float64), H)
+    q = T.from_numpy(qkv).cuda().bfloat16()
+    ctx, lse = ops.attention_lse(q, H)
+    dqkv = ops.attention_bwd(q, ctx, T.from_numpy(dctx).cuda().bfloat16(), lse, H).float().cpu().numpy()
+    assert np.isfinite(dqkv).all()
+    scale = max(np.abs(dqkv_ref).max(), 1e-30)
+    assert np.abs(dqkv - dqkv_ref).max() <= 2e-2 * scale, (np.abs(dqkv - dqkv_ref).max(), scale)
+    d = H * 64
+    dead_q = ~(dctx != 0).any(axis=2)                     # queries with no incoming gradient: dq is exactly 0
+    assert (dqkv[:, :, :d][dead_q] == 0).all()
+    if live == "none":
+        assert (dqkv == 0).all()
+
+
 @pytest.mark.parametrize("d", [128, 384])
 def test_layernorm_backward(T, gww, d):
     from gw_whisper_amd import ops
