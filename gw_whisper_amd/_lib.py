@@ -66,10 +66,10 @@ SIGNATURES = {
     "gww_train_saved_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "gww_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "gww_encoder_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
-                                            C.c_size_t, C.c_void_p, C.c_void_p]),
+                                            C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "gww_encoder_train_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                              C.c_void_p, C.POINTER(DoraTarget), C.c_int, C.c_void_p, C.c_void_p,
-                                             C.c_void_p]),
+                                             C.c_int, C.c_void_p]),
     "gww_attention_bwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gww_attention_lse_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -658,7 +658,7 @@ extern "C" size_t gww_train_workspace_bytes(const gww_encoder* e, int batch) {
 
 extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int batch, void* workspace,
                                          size_t workspace_bytes, void* saved, size_t saved_bytes,
-                                         float* last_hidden, void* stream) {
+                                         float* last_hidden, int pooled, void* stream) {
   GWW_REQUIRE(e && mel && workspace && saved && last_hidden, "gww_encoder_train_forward: NULL argument");
   if (!e->ready) return fail(GWW_ERR_STATE, "gww_encoder_train_forward: weights not set");
   GWW_REQUIRE(batch > 0, "gww_encoder_train_forward: batch must be positive");
@@ -700,6 +700,22 @@ extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int b
     if (fast) GWW_TRY(launch_gemm_astat(h1, d, nullptr, nullptr, nullptr, nullptr, W.wqkv, W.bqkv, qkv, M, 3 * d, d, EPI_BIAS, 0, s));
     else GWW_TRY(launch_gemm_bf16(h1, d, W.wqkv, W.bqkv, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0, s, 1));
     GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s, lse));
+    if (pooled && l == L - 1) {
+      // Only token T-1 of the output is used (Signal_vs_Noise/src/model.py:25-26), and past the last attention
+      // every op is row-wise: run out_proj / LN2 / fc1 / GELU / fc2 / final LN on the B last-token rows alone.
+      // x_mid, z and x_in[L] of this layer are saved COMPACT ([B, .]) -- the pooled backward expects exactly that.
+      float* xl = (float*)(base + w.dx);   // x_in[L-1] rows (b, T-1); the gradient buffers are idle in the forward
+      GWW_HIP(hipMemcpy2DAsync(xl, (size_t)d * 4, x_in(l) + (size_t)(T - 1) * d, (size_t)T * d * 4, (size_t)d * 4, B,
+                               hipMemcpyDeviceToDevice, s));
+      GWW_TRY(launch_gemm_bf16((const unsigned short*)ctx + (size_t)(T - 1) * d, (long)T * d, W.wo, W.bo, xl, nullptr,
+                               x_mid, B, d, d, EPI_RESID, 0, s, 0));
+      GWW_TRY(launch_layernorm(x_mid, W.ln2w, W.ln2b, h2, 1, B, d, s));
+      GWW_TRY(launch_gemm_bf16(h2, d, W.w1, W.b1, nullptr, nullptr, z, B, F, d, EPI_BIAS, 0, s, 0));
+      GWW_TRY(launch_gelu_bf16(z, nullptr, f1, (((long)B * F + 7) / 8) * 8, s));
+      GWW_TRY(launch_gemm_bf16(f1, F, W.w2, W.b2, x_mid, nullptr, x_in(L), B, d, F, EPI_RESID, 0, s, 0));
+      GWW_TRY(launch_layernorm(x_in(L), e->lnw, e->lnb, last_hidden, 0, B, d, s));
+      return GWW_OK;
+    }
     GWW_TRY(launch_gemm_bf16(ctx, d, W.wo, W.bo, x_in(l), nullptr, x_mid, M, d, d, EPI_RESID, 0, s, 1));
     GWW_TRY(launch_layernorm(x_mid, W.ln2w, W.ln2b, h2, 1, M, d, s));
     if (fast) GWW_TRY(launch_gemm_astat(h2, d, nullptr, nullptr, nullptr, nullptr, W.w1, W.b1, z, M, F, d, EPI_BIAS, 0, s));
@@ -720,7 +736,7 @@ extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int b
 extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* workspace, size_t workspace_bytes,
                                           const void* saved, size_t saved_bytes, const float* d_last_hidden,
                                           const gww_dora_target* targets, int n_targets, float* d_x0,
-                                          float* d_mel, void* stream) {
+                                          float* d_mel, int pooled, void* stream) {
   GWW_REQUIRE(e && workspace && saved && d_last_hidden, "gww_encoder_train_backward: NULL argument");
   GWW_REQUIRE(batch > 0 && n_targets >= 0 && (n_targets == 0 || targets), "gww_encoder_train_backward: bad argument");
   const SavedLayout sl = saved_layout(e->cfg, batch);
@@ -756,8 +772,8 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
       return launch_gemm_fulln(A, lda, Wt, nullptr, nullptr, Cout, M, N, K, EPI_BIAS, 0, s);
     return launch_gemm_bf16(A, lda, Wt, nullptr, nullptr, nullptr, Cout, M, N, K, EPI_BIAS, 0, s, 1);
   };
-  // final LayerNorm backward -> dx (grad w.r.t. x_in[L])
-  GWW_TRY(launch_ln_bwd(x_in(L), e->lnw, d_last_hidden, 1, dx, 0, dxb, M, d, s));
+  // final LayerNorm backward -> dx (grad w.r.t. x_in[L]); pooled: on the B last-token rows only
+  GWW_TRY(launch_ln_bwd(x_in(L), e->lnw, d_last_hidden, 1, dx, 0, dxb, pooled ? B : M, d, s));
   for (int l = L - 1; l >= 0; --l) {
     const LayerW& W = e->layers[l];
     const char* lb = sv + (size_t)l * sl.layer_stride;
@@ -767,6 +783,40 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
     const void* ctx = lb + sl.ctx;
     const float* x_mid = (const float*)(lb + sl.x_mid);
     const void* z = lb + sl.z;
+    if (pooled && l == L - 1) {
+      // ---- last layer of a pooled step: everything above the attention lives on the B last-token rows
+      // (x_mid, z, x_in[L] were saved compact by the pooled forward); the attention backward then sees a dctx
+      // that is zero except for row T-1 of every segment and skips the dead query tiles.
+      GWW_TRY(launch_gemm_bf16(dxb, d, W.w2T, nullptr, nullptr, nullptr, dbig, B, F, d, EPI_BIAS, 0, s, 0));
+      GWW_TRY(launch_gelu_bf16(z, dbig, dbig, (((long)B * F + 7) / 8) * 8, s));
+      GWW_TRY(launch_gemm_bf16(dbig, F, W.w1T, nullptr, nullptr, nullptr, dh, B, d, F, EPI_BIAS, 0, s, 0));
+      GWW_TRY(launch_ln_bwd(x_mid, W.ln2w, dh, 0, dx, 1, dxb, B, d, s));
+      const unsigned short* ctx_last = (const unsigned short*)ctx + (size_t)(T - 1) * d;
+      bool have_y = false;
+      for (int i = 0; i < n_targets; ++i) {
+        const gww_dora_target& t = targets[i];
+        if (t.layer != l || t.proj != 3) continue;
+        if (!have_y) {   // y = x_mid - x_in on the last-token rows
+          float* xl = (float*)dbig;
+          GWW_HIP(hipMemcpy2DAsync(xl, (size_t)d * 4, x_in(l) + (size_t)(T - 1) * d, (size_t)T * d * 4, (size_t)d * 4,
+                                   B, hipMemcpyDeviceToDevice, s));
+          GWW_TRY(launch_sub_f32_bf16(x_mid, xl, dh, (long)B * d, s));
+          have_y = true;
+        }
+        GWW_TRY(launch_dora_grads(ctx_last, (long)T * d, dxb, dh, d, W.bo, 1.0f, t.scaling, t.A, t.B, t.mag, t.nrm,
+                                  t.dA, t.dB, t.dm, B, d, t.r, s));
+      }
+      // d(ctx) rows (b, T-1) -> the dense, otherwise zero dctx
+      GWW_TRY(launch_gemm_bf16(dxb, d, W.woT, nullptr, nullptr, nullptr, dh, B, d, d, EPI_BIAS, 0, s, 0));
+      GWW_HIP(hipMemsetAsync(dctx, 0, (size_t)M * d * 2, s));
+      GWW_HIP(hipMemcpy2DAsync((unsigned short*)dctx + (size_t)(T - 1) * d, (size_t)T * d * 2, dh, (size_t)d * 2,
+                               (size_t)d * 2, B, hipMemcpyDeviceToDevice, s));
+      // the residual gradient likewise: compact dx -> row T-1 of a zero dense dx
+      GWW_HIP(hipMemcpyAsync(dbig, dx, (size_t)B * d * 4, hipMemcpyDeviceToDevice, s));
+      GWW_HIP(hipMemsetAsync(dx, 0, (size_t)M * d * 4, s));
+      GWW_HIP(hipMemcpy2DAsync(dx + (size_t)(T - 1) * d, (size_t)T * d * 4, dbig, (size_t)d * 4, (size_t)d * 4, B,
+                               hipMemcpyDeviceToDevice, s));
+    } else {
     // fc2 / GELU / fc1 / LN2   (x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))))
     GWW_TRY(gemm_dx(dxb, d, W.w2T, dbig, F, d));
     GWW_TRY(launch_gelu_bf16(z, dbig, dbig, ((M * F + 7) / 8) * 8, s));
@@ -787,6 +837,7 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
       }
     }
     GWW_TRY(gemm_dx(dxb, d, W.woT, dctx, d, d));
+    }
     GWW_TRY(launch_attention_bwd_bf16(qkv, ctx, dctx, lse, Dv, dqkv, B, T, H, s));
     for (int i = 0; i < n_targets; ++i) {
       const gww_dora_target& t = targets[i];

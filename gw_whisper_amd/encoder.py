@@ -263,14 +263,17 @@ class WhisperEncoder(nn.Module):
         return {lib().gww_encoder_trace_class_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
 
     def forward(self, input_features, attention_mask=None, **kwargs):
-        if torch.is_grad_enabled() and (self._has_trainable_adapters() or
-                                        (torch.is_tensor(input_features) and input_features.requires_grad)):
+        if self._wants_grad(input_features):
             # DoRA training step: HIP forward that keeps activations + HIP backward (training.py)
             from .training import encoder_train_forward
             self._check_input(input_features)
             return BaseModelOutput(last_hidden_state=encoder_train_forward(self, input_features))
         hidden, _ = self.forward_raw(input_features, want_hidden=True, want_last=False)
         return BaseModelOutput(last_hidden_state=hidden)
+
+    def _wants_grad(self, input_features) -> bool:
+        return torch.is_grad_enabled() and (self._has_trainable_adapters() or
+                                            (torch.is_tensor(input_features) and input_features.requires_grad))
 
     def _has_trainable_adapters(self) -> bool:
         for layer in self.layers:
@@ -292,5 +295,10 @@ class WhisperEncoder(nn.Module):
 
     def last_token(self, input_features) -> torch.Tensor:
         """``self(mel).last_hidden_state[:, -1, :]`` without materialising the other
-        1499 rows of the final LayerNorm (reference ``src/model.py:25-26``)."""
+        1499 rows of the final LayerNorm (reference ``src/model.py:25-26``).  Differentiable: with trainable
+        adapters (or an input that requires grad) this is the pooled training step of ``training.py``."""
+        if self._wants_grad(input_features):
+            from .training import encoder_train_forward
+            self._check_input(input_features)
+            return encoder_train_forward(self, input_features, pooled=True)
         return self.forward_raw(input_features, want_hidden=False, want_last=True)[1]

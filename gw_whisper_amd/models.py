@@ -10,8 +10,9 @@ load unchanged -- SURVEY.md appendix A) and forward semantics as
 The reference's own classes also work unchanged on a ``gw_whisper_amd`` encoder (they only
 call ``encoder(mel).last_hidden_state[:, -1, :]`` and read ``encoder.config.d_model``);
 these copies exist because the reference tree does not travel to the GPU box, and they use
-the encoder's ``last_token`` fast path (only token 1499 goes through the final LayerNorm)
-when it is available.  The MLP heads are plain ``torch.nn`` on the GPU.
+the encoder's ``last_token`` fast path when it is available (inference: only token 1499 goes
+through the final LayerNorm; training: the last layer's row-wise ops and their backward run on
+the pooled rows only).  The MLP heads are plain ``torch.nn`` on the GPU.
 """
 
 from __future__ import annotations
@@ -22,7 +23,7 @@ import torch.nn as nn
 
 def _pooled(encoder, mel):
     fast = getattr(encoder, "last_token", None)
-    if fast is not None and not torch.is_grad_enabled():
+    if fast is not None:
         return fast(mel)
     return encoder(mel).last_hidden_state[:, -1, :]
 

@@ -40,7 +40,7 @@ def dora_targets(encoder):
 
 class _EncoderTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, encoder, mel, *params):
+    def forward(ctx, encoder, mel, pooled, *params):
         enc = encoder
         c = enc.config
         x = mel.to(torch.float32).contiguous()
@@ -51,12 +51,13 @@ class _EncoderTrain(torch.autograd.Function):
             h = enc._ensure_handle()
             ws = torch.empty((lib().gww_train_workspace_bytes(h, B),), dtype=torch.uint8, device=dev)
             saved = torch.empty((lib().gww_train_saved_bytes(h, B),), dtype=torch.uint8, device=dev)
-            hidden = torch.empty((B, c.max_source_positions, c.d_model), dtype=torch.float32, device=dev)
+            shape = (B, c.d_model) if pooled else (B, c.max_source_positions, c.d_model)
+            hidden = torch.empty(shape, dtype=torch.float32, device=dev)
             check(lib().gww_encoder_train_forward(h, x.data_ptr(), B, ws.data_ptr(), ws.numel(), saved.data_ptr(),
-                                                  saved.numel(), hidden.data_ptr(),
+                                                  saved.numel(), hidden.data_ptr(), int(pooled),
                                                   torch.cuda.current_stream().cuda_stream),
                   "gww_encoder_train_forward")
-        ctx.enc, ctx.B, ctx.ws, ctx.saved = enc, B, ws, saved
+        ctx.enc, ctx.B, ctx.ws, ctx.saved, ctx.pooled = enc, B, ws, saved, bool(pooled)
         ctx.n_params = len(params)
         ctx.mel_shape = tuple(x.shape)
         return hidden
@@ -85,18 +86,20 @@ class _EncoderTrain(torch.autograd.Function):
             check(lib().gww_encoder_train_backward(enc._ensure_handle(), B, ctx.ws.data_ptr(), ctx.ws.numel(),
                                                    ctx.saved.data_ptr(), ctx.saved.numel(), d_hidden.data_ptr(), arr,
                                                    len(targets), None, d_mel.data_ptr() if d_mel is not None else None,
-                                                   torch.cuda.current_stream().cuda_stream),
+                                                   int(ctx.pooled), torch.cuda.current_stream().cuda_stream),
                   "gww_encoder_train_backward")
         flat = []
         for dA, dB, dm in grads:
             flat += [dA, dB, dm]
         assert len(flat) == ctx.n_params
         ctx.ws = ctx.saved = None
-        return (None, d_mel, *flat)
+        return (None, d_mel, None, *flat)
 
 
-def encoder_train_forward(encoder, mel: torch.Tensor) -> torch.Tensor:
-    """last_hidden_state [B, 1500, d] with autograd through the DoRA parameters and, when ``mel.requires_grad``,
+def encoder_train_forward(encoder, mel: torch.Tensor, pooled: bool = False) -> torch.Tensor:
+    """last_hidden_state [B, 1500, d] -- or, with ``pooled``, its last token [B, d] (what every classifier of the
+    reference reads, ``Signal_vs_Noise/src/model.py:25-26``; the last layer's row-wise ops and their backward then run
+    on B rows instead of B * 1500) -- with autograd through the DoRA parameters and, when ``mel.requires_grad``,
     through the conv stem to the input features."""
     if encoder.precision != "bf16":
         raise _lib.GwwError("the training step is implemented for precision='bf16'")
@@ -104,4 +107,4 @@ def encoder_train_forward(encoder, mel: torch.Tensor) -> torch.Tensor:
     for _, _, mod in dora_targets(encoder):
         params += [mod.lora_A[mod.adapter].weight, mod.lora_B[mod.adapter].weight,
                    mod.lora_magnitude_vector[mod.adapter].weight]
-    return _EncoderTrain.apply(encoder, mel, *params)
+    return _EncoderTrain.apply(encoder, mel, bool(pooled), *params)

@@ -174,11 +174,16 @@ size_t gww_train_saved_bytes(const gww_encoder* enc, int batch);
 size_t gww_train_workspace_bytes(const gww_encoder* enc, int batch);
 int gww_encoder_train_forward(gww_encoder* enc, const float* mel, int batch, void* workspace,
                               size_t workspace_bytes, void* saved, size_t saved_bytes,
-                              float* last_hidden, void* stream);
+                              float* last_hidden, int pooled, void* stream);
 int gww_encoder_train_backward(gww_encoder* enc, int batch, void* workspace, size_t workspace_bytes,
                                const void* saved, size_t saved_bytes, const float* d_last_hidden,
                                const gww_dora_target* targets, int n_targets, float* d_x0, float* d_mel,
-                               void* stream);
+                               int pooled, void* stream);
+/* pooled != 0: the caller only uses token T-1 of the output, as every classifier of the reference does
+ * (Signal_vs_Noise/src/model.py:25-26 `last_hidden_state[:, -1, :]`).  last_hidden and d_last_hidden are then
+ * [batch, d]; everything above the last layer's attention (out_proj, LN2, fc1, GELU, fc2, final LN and their
+ * backward) runs on those `batch` rows instead of batch*T, and the attention backward skips the query tiles
+ * without gradient.  The forward and the backward of one step must use the same `pooled`. */
 /* d_x0 (optional): fp32 [batch*T, d] gradient w.r.t. the conv-stem output.  d_mel (optional): fp32
  * [batch, n_mels, t_in] gradient w.r.t. the input features through the conv stem -- the encoder call is
  * differentiable w.r.t. its input, as MLGWSC-1/train.py:494-504 (trainable Q-adapter in front of the frozen

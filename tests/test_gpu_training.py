@@ -168,10 +168,12 @@ def test_dora_parameter_gradients(T, gww, d, M):
 
 @pytest.mark.parametrize("projs", [("q_proj", "k_proj", "v_proj"), ("q_proj", "k_proj", "v_proj", "out_proj")],
                          ids=["qkv", "qkvo"])
-def test_training_step_matches_finite_differences(T, gww, projs):
+@pytest.mark.parametrize("pooled", [False, True], ids=["hidden", "last_token"])
+def test_training_step_matches_finite_differences(T, gww, projs, pooled):
     """loss.backward() through the HIP encoder (DoRA on q, k, v [, out_proj] of a 2-layer d=128 encoder;
     the two target sets of Signal_vs_Noise/src/train.py:230-237 and MLGWSC-1/train.py:695) against
-    central finite differences of the fp64 oracle forward with the weight norm frozen (detached)."""
+    central finite differences of the fp64 oracle forward with the weight norm frozen (detached).
+    ``pooled``: through ``encoder.last_token`` (what models.py calls), whose last layer runs on the pooled rows only."""
     from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
     from gw_whisper_amd.peft import LoraConfig, get_peft_model
     cfg = oenc.EncCfg(128, 2, 2, 512)
@@ -193,9 +195,13 @@ def test_training_step_matches_finite_differences(T, gww, projs):
     wloss = rng.standard_normal((2, 128))
 
     # ---- GPU: loss = sum(w * last_token); backward through libgww
-    hidden = peft(T.from_numpy(mel).cuda()).last_hidden_state
-    assert hidden.requires_grad
-    loss = (hidden[:, -1, :] * T.from_numpy(wloss).cuda().float()).sum()
+    if pooled:
+        last = peft.last_token(T.from_numpy(mel).cuda())
+        assert last.shape == (2, 128)
+    else:
+        last = peft(T.from_numpy(mel).cuda()).last_hidden_state[:, -1, :]
+    assert last.requires_grad
+    loss = (last * T.from_numpy(wloss).cuda().float()).sum()
     loss.backward()
     grads = {}
     for name in targets:
@@ -255,9 +261,20 @@ def test_whisper_small_dora_step_runs(T, gww):
     print(f"whisper-small training forward vs inference forward: max diff {err:.3e}")
     assert err < 0.15
     out[:, -1, :].square().sum().backward()
+    dense = {}
     for n, p in peft.named_parameters():
         if "lora_" in n:
             assert p.grad is not None and T.isfinite(p.grad).all() and p.grad.abs().max() > 0, n
+            dense[n] = p.grad.clone()
+            p.grad = None
+    # the pooled step (encoder.last_token) is the same function of the adapters
+    last = peft.last_token(mel)
+    assert (last.detach() - out.detach()[:, -1, :]).abs().max().item() < 0.05
+    last.square().sum().backward()
+    for n, p in peft.named_parameters():
+        if "lora_" in n:
+            scale = dense[n].abs().max().item()
+            assert (p.grad - dense[n]).abs().max().item() < 0.05 * scale + 1e-6, n
 
 
 def test_input_gradient_through_the_conv_stem(T, gww):
