@@ -79,6 +79,11 @@ SIGNATURES = {
     "gww_dora_grads": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_float,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "gww_dora_grads_multi": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long, C.c_int,
+                                       C.POINTER(C.c_long), C.POINTER(C.c_void_p), C.POINTER(C.c_float),
+                                       C.POINTER(C.c_float), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_long, C.c_int, C.c_void_p]),
     "gww_dora_merge_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gww_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long,

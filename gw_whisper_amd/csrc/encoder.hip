@@ -37,6 +37,12 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
 int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
                       float yscale, float scaling, const float* A, const float* Bm, const float* mag,
                       const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s);
+int launch_dora_grads_multi(const void* X, long ldx, const void* dY, const void* Y, long ldy, int np,
+                            const long* col_off, const float* const* bias_st, const float* yscale,
+                            const float* scaling, const float* const* A, const float* const* Bm,
+                            const float* const* mag, const float* const* nrm, float* const* dA, float* const* dB,
+                            float* const* dm, long M, int d, hipStream_t s, void* scratch, size_t scratch_bytes);
+size_t dora_grads_scratch_bytes(int np, int d);
 int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* D,
                               void* dqkv, int B, int T, int H, hipStream_t s);
 int launch_mel_to_tokens(const float* mel, void* out, int out_bf16, int B, int C, int T, hipStream_t s);
@@ -623,7 +629,7 @@ SavedLayout saved_layout(const gww_enc_cfg& c, int B) {
   return s;
 }
 struct TrainWs {
-  size_t melT, c1, h2, f1, dx, dxb, dbig, dh, dctx, dqkv, Dv, z1, col1, total;
+  size_t melT, c1, h2, f1, dx, dxb, dbig, dh, dctx, dqkv, Dv, z1, col1, dgs, dgs_bytes, total;
 };
 TrainWs train_ws(const gww_enc_cfg& c, int B) {
   const size_t d = c.d_model, F = c.ffn, Tin = c.t_in, T = c.t_in / 2, C = c.n_mels, H = c.n_heads;
@@ -644,6 +650,8 @@ TrainWs train_ws(const gww_enc_cfg& c, int B) {
   w.Dv = take((size_t)B * H * (T + (T + 63) / 64) * 4);   // row dots + live-tile flags
   w.z1 = take(((size_t)B * (Tin + 2) + 256) * d * 2);            // stem backward: conv1 pre-activation / its gradient
   w.col1 = take(((size_t)B * (Tin + 2) + 256) * kConv1Kpad * 2); // stem backward: conv1 taps side by side
+  w.dgs_bytes = (d == 384 || d == 512) ? dora_grads_scratch_bytes(3, (int)d) : 0;   // DoRA-gradient partial sums
+  w.dgs = take(w.dgs_bytes);
   w.total = off;
   return w;
 }
@@ -772,6 +780,8 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
       return launch_gemm_fulln(A, lda, Wt, nullptr, nullptr, Cout, M, N, K, EPI_BIAS, 0, s);
     return launch_gemm_bf16(A, lda, Wt, nullptr, nullptr, nullptr, Cout, M, N, K, EPI_BIAS, 0, s, 1);
   };
+  bool multi_ok = (d == 384 || d == 512) && !getenv("GWW_DORA_OLD");
+  for (int i = 0; i < n_targets; ++i) multi_ok = multi_ok && targets[i].r == 8;
   // final LayerNorm backward -> dx (grad w.r.t. x_in[L]); pooled: on the B last-token rows only
   GWW_TRY(launch_ln_bwd(x_in(L), e->lnw, d_last_hidden, 1, dx, 0, dxb, pooled ? B : M, d, s));
   for (int l = L - 1; l >= 0; --l) {
@@ -839,13 +849,36 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
     GWW_TRY(gemm_dx(dxb, d, W.woT, dctx, d, d));
     }
     GWW_TRY(launch_attention_bwd_bf16(qkv, ctx, dctx, lse, Dv, dqkv, B, T, H, s));
-    for (int i = 0; i < n_targets; ++i) {
-      const gww_dora_target& t = targets[i];
-      if (t.layer != l || t.proj == 3) continue;
-      const long off = (long)t.proj * d;   // q | k | v section
-      GWW_TRY(launch_dora_grads(h1, d, (const unsigned short*)dqkv + off, (const unsigned short*)qkv + off, 3L * d,
-                                W.bqkv + off, t.proj == 0 ? 0.125f : 1.0f, t.scaling, t.A, t.B, t.mag, t.nrm, t.dA,
-                                t.dB, t.dm, M, d, t.r, s));
+    if (multi_ok) {
+      // q / k / v adapters of this layer read the same h1: one pass over h1, dqkv and qkv on the matrix cores
+      long off[3];
+      const float *bias[3], *Aa[3], *Bb[3], *mg[3], *nr[3];
+      float ysc[3], scl[3], *dAa[3], *dBb[3], *dmm[3];
+      int np = 0;
+      for (int i = 0; i < n_targets; ++i) {
+        const gww_dora_target& t = targets[i];
+        if (t.layer != l || t.proj == 3) continue;
+        GWW_REQUIRE(np < 3, "gww_encoder_train_backward: duplicate q/k/v target in layer %d", l);
+        off[np] = (long)t.proj * d;
+        bias[np] = W.bqkv + off[np];
+        ysc[np] = t.proj == 0 ? 0.125f : 1.0f;
+        scl[np] = t.scaling;
+        Aa[np] = t.A; Bb[np] = t.B; mg[np] = t.mag; nr[np] = t.nrm;
+        dAa[np] = t.dA; dBb[np] = t.dB; dmm[np] = t.dm;
+        ++np;
+      }
+      if (np > 0)
+        GWW_TRY(launch_dora_grads_multi(h1, d, dqkv, qkv, 3L * d, np, off, bias, ysc, scl, Aa, Bb, mg, nr, dAa, dBb, dmm, M,
+                                        d, s, base + w.dgs, w.dgs_bytes));
+    } else {
+      for (int i = 0; i < n_targets; ++i) {
+        const gww_dora_target& t = targets[i];
+        if (t.layer != l || t.proj == 3) continue;
+        const long off = (long)t.proj * d;   // q | k | v section
+        GWW_TRY(launch_dora_grads(h1, d, (const unsigned short*)dqkv + off, (const unsigned short*)qkv + off, 3L * d,
+                                  W.bqkv + off, t.proj == 0 ? 0.125f : 1.0f, t.scaling, t.A, t.B, t.mag, t.nrm, t.dA,
+                                  t.dB, t.dm, M, d, t.r, s));
+      }
     }
     // below layer 0 the gradient only continues into the conv stem: skip it when nobody asked for d_x0 / d_mel
     if (l == 0 && !d_x0 && !d_mel) break;

@@ -570,14 +570,27 @@ __global__ __launch_bounds__(256) void k_dora_grads_rb(const unsigned short* __r
   }
 }
 
+int launch_dora_grads_multi(const void* X, long ldx, const void* dY, const void* Y, long ldy, int np,
+                            const long* col_off, const float* const* bias_st, const float* yscale,
+                            const float* scaling, const float* const* A, const float* const* Bm,
+                            const float* const* mag, const float* const* nrm, float* const* dA, float* const* dB,
+                            float* const* dm, long M, int d, hipStream_t s, void* scratch, size_t scratch_bytes);
+size_t dora_grads_scratch_bytes(int np, int d);
+
 int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
                       float yscale, float scaling, const float* A, const float* Bm, const float* mag,
                       const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s) {
   GWW_REQUIRE(r == 8 && (d == 128 || d == 384 || d == 512 || d == 768 || d == 1024 || d == 1280),
               "dora_grads: only r = 8 and d in {128, 384, 512, 768, 1024, 1280} (got d=%d r=%d)", d, r);
   if (M == 0) return GWW_OK;
-  static const bool old_kernel = getenv("GWW_DORA_OLD") != nullptr;   // comparison aid
-  if (d <= 768 && d != 128 && !old_kernel) {
+  static const int old_kernel = getenv("GWW_DORA_OLD") ? atoi(getenv("GWW_DORA_OLD")) : 0;   // comparison aid: 1 = VALU
+  // kernels only, 2 = register-blocked VALU kernel instead of the MFMA kernel
+  if ((d == 384 || d == 512) && !old_kernel) {   // matrix-core kernel (dora_grads.hip)
+    const long off = 0;
+    return launch_dora_grads_multi(X, ldx, dY, Y, ldy, 1, &off, &bias_st, &yscale, &scaling, &A, &Bm, &mag, &nrm, &dA, &dB,
+                                   &dm, M, d, s, nullptr, 0);
+  }
+  if (d <= 768 && d != 128 && old_kernel != 1) {
     static const long nb_env = getenv("GWW_DORA_BLOCKS") ? atol(getenv("GWW_DORA_BLOCKS")) : 0;   // tuning aid
     const int rt = d <= 512 ? 16 : 8;
     long nb = cdiv(M, rt);

@@ -293,6 +293,28 @@ def gelu_bf16(z, dgelu=None):
     return out
 
 
+def dora_grads_multi(x, dy, y, col_off, bias_st, yscale, scaling, A, B, mag, nrm):
+    """[(dA, dB, dm)] of up to three DoRA projections that read the same x (q, k, v of a layer) in one pass:
+    x bf16 [M, d]; dy, y bf16 [M, W] with projection p in columns col_off[p] .. col_off[p] + d; the other arguments
+    are per-projection lists.  d in {384, 512}, r = 8."""
+    import ctypes as C
+    x, dy, y = (_dev(t, torch.bfloat16) for t in (x, dy, y))
+    M, d = x.shape
+    n = len(col_off)
+    keep = [[_dev(t, torch.float32) for t in lst] for lst in (bias_st, A, B, mag, nrm)]
+    out = [(torch.zeros((8, d), dtype=torch.float32, device=x.device),
+            torch.zeros((d, 8), dtype=torch.float32, device=x.device),
+            torch.zeros((d,), dtype=torch.float32, device=x.device)) for _ in range(n)]
+    ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    with torch.cuda.device(x.device):
+        check(lib().gww_dora_grads_multi(x.data_ptr(), x.stride(0), dy.data_ptr(), y.data_ptr(), dy.stride(0), n,
+                                         (C.c_long * n)(*col_off), ptrs(keep[0]), (C.c_float * n)(*yscale),
+                                         (C.c_float * n)(*scaling), ptrs(keep[1]), ptrs(keep[2]), ptrs(keep[3]),
+                                         ptrs(keep[4]), ptrs([o[0] for o in out]), ptrs([o[1] for o in out]),
+                                         ptrs([o[2] for o in out]), M, d, _stream()), "gww_dora_grads_multi")
+    return out
+
+
 def dora_grads(x, dy, y, bias_st, yscale, scaling, A, B, mag, nrm):
     """(dA [r,d], dB [d,r], dm [d]) of one DoRA projection; x, dy, y bf16 [M, d]."""
     x, dy, y = (_dev(t, torch.bfloat16) for t in (x, dy, y))

@@ -281,6 +281,15 @@ int gww_gelu_bf16(const void* z, const void* dgelu_or_null, void* out, long n, v
 int gww_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
                    float yscale, float scaling, const float* A, const float* B, const float* mag,
                    const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, void* stream);
+/* The same for np (1..3) projections that read the SAME X -- q, k and v of a layer (peft 0.12.0 dora.py; targets of
+ * Signal_vs_Noise/src/train.py:230-237) -- in one pass on the matrix cores (dora_grads.hip); d in {384, 512}, r = 8.
+ * Projection p reads dY / Y at column col_off[p] of rows with stride ldy; all arrays have np entries (host memory,
+ * device pointers inside).  Gradients are accumulated. */
+int gww_dora_grads_multi(const void* X, long ldx, const void* dY, const void* Y, long ldy, int np,
+                         const long* col_off, const float* const* bias_st, const float* yscale,
+                         const float* scaling, const float* const* A, const float* const* B,
+                         const float* const* mag, const float* const* nrm, float* const* dA, float* const* dB,
+                         float* const* dm, long M, int d, void* stream);
 /* fp32 -> bf16 (round to nearest even), n elements */
 int gww_cast_f32_bf16(const float* x, void* y, long n, void* stream);
 
