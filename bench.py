@@ -282,6 +282,11 @@ def main():
             if args.split:
                 enc.set_split(True)
     assert torch.isfinite(out[1]).all()
+    # extra (never `value`): the classifiers of the reference only read token 1499 (src/model.py:25-26); with
+    # want_hidden=False the last layer runs on the B pooled rows above its attention.  Reported beside the full
+    # forward, which stays the headline metric.
+    with torch.no_grad():
+        pooled_ms = time_kernel(lambda: enc.forward_raw(mel, want_hidden=False, want_last=True), iters=5, warm=2)
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -317,6 +322,9 @@ def main():
             "frontend_qscan": {"kernel": "rDFT GEMM + k_qscan_tiles + k_qscan_interp (parity unpinned, DESIGN.md section 2)",
                                "ms_per_batch": q_ms, "windows_per_s": 2 * B / q_ms * 1e3,
                                "config": f"{2 * B} x 2048 samples, qrange [4, 128], 148 tiles rows, 128 x 128 output"},
+            "pooled_classify": {"what": "encoder.last_token(): same encoder, only last_hidden_state[:, -1] produced "
+                                        "(last layer: one query tile of attention, row-wise ops on B rows)",
+                                "ms_per_batch": pooled_ms, "segments_per_s_per_gpu": B / pooled_ms * 1e3},
             "dora_step_ms": train["ms"] if train else None,
             "dora_step": train,
         }

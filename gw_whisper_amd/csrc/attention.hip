@@ -68,7 +68,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attention_bf16(const unsigned short* __restrict__ qkv,
                                                            unsigned short* __restrict__ ctx,
                                                            float* __restrict__ lse, int T, int H,
-                                                           int q_tiles) {
+                                                           int q_tiles, int qt0) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KB * DH * 2];   // 32 KB
   constexpr int TILE_BYTES = KB * DH * 2;
   auto Ks = [&](int buf) -> unsigned char* { return lds + buf * TILE_BYTES; };
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attention_bf16(con
   // K / V (384 KB) -- run on ONE XCD back to back and K / V come from HBM once instead of once per XCD.
   const unsigned nblk = gridDim.x, per = nblk >> 3;
   const unsigned wid = blockIdx.x < 8 * per ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
-  const int qt = wid % q_tiles;
+  const int qt = qt0 + wid % q_tiles;   // q_tiles = query tiles in THIS launch, starting at tile qt0
   const int bh = wid / q_tiles;
   const int b = bh / H, h = bh - b * H;
   const int d = H * DH;
@@ -267,7 +267,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attention_bf16(con
   ASTAMP_FLUSH
 }
 
-int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipStream_t s, float* lse) {
+// last_tile_only: compute only the query tile that holds token T - 1 (the other rows of ctx are left untouched) --
+// the pooled forward needs nothing else of the last layer's attention.
+int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipStream_t s, float* lse,
+                          bool last_tile_only) {
   GWW_REQUIRE(qkv && ctx, "attention_bf16: NULL operand");
   GWW_REQUIRE(B >= 0 && T > 0 && H > 0, "attention_bf16: bad shape B=%d T=%d H=%d", B, T, H);
   GWW_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)ctx) & 15) == 0, "attention_bf16: 16-byte alignment");
@@ -276,15 +279,16 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
   // 128 query rows per workgroup, two workgroups per CU; the 256-row form (one per CU, K / V streamed once per
   // 256 queries) measures 5 % slower at T = 1500 -- the kernel is issue-bound, not L2-bound
   const int nw = nw_env == 8 ? 8 : 4;
-  const int q_tiles = (T + nw * 32 - 1) / (nw * 32);
+  const int all_tiles = (T + nw * 32 - 1) / (nw * 32);
+  const int q_tiles = last_tile_only ? 1 : all_tiles, qt0 = last_tile_only ? all_tiles - 1 : 0;
   const long blocks = (long)q_tiles * B * H;
   GWW_REQUIRE(blocks < 2147483647L, "attention_bf16: grid too large");
   if (nw == 8)
     hipLaunchKernelGGL(k_attention_bf16<8>, dim3((unsigned)blocks), dim3(512), 0, s,
-                       (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles);
+                       (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles, qt0);
   else
     hipLaunchKernelGGL(k_attention_bf16<4>, dim3((unsigned)blocks), dim3(256), 0, s,
-                       (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles);
+                       (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles, qt0);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }

@@ -483,12 +483,15 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   GWW_HIP(hipMemsetAsync((char*)melT + (size_t)B * (Tin + 2) * C * es, 0, kConv1Kpad * es, s));
   GWW_HIP(hipMemsetAsync(c1, 0, (size_t)d * es, s));   // zero row 0 of batch 0 (token -1)
   // A-stationary kernels (A panel in registers, fused residual-add + LayerNorm prologue) for K = d <= 512
-  // GWW_GENERIC_PATH (debug aid): bit 0 = generic layer GEMMs, bit 1 = generic conv1, bit 2 = generic conv2, bit 3 = unfused MLP
+  // GWW_GENERIC_PATH (debug aid): bit 0 = generic layer GEMMs, bit 1 = generic conv1, bit 2 = generic conv2, bit 3 = unfused MLP,
+  // bit 4 = stand-alone QKV, bit 5 = no pooled last layer
   static const int generic_mask = getenv("GWW_GENERIC_PATH") ? atoi(getenv("GWW_GENERIC_PATH")) : 0;
   const bool astat = bf && (d == 384 || d == 512) && F % 128 == 0 && !(generic_mask & 1);
   const bool mlp_fused = astat && d == 384 && F <= 1536 && !(generic_mask & 8);   // bit 3 = separate fc1 / fc2 kernels
   const bool fuse_qkv = mlp_fused && !(generic_mask & 16);                          // bit 4 = stand-alone LN1 + QKV kernels
   bool qkv_done = false;
+  // only the last token wanted: the last layer runs on B rows above its attention (bit 5 of the mask disables it)
+  const bool pooled = astat && !last_hidden && last_token && T >= 3 && !(generic_mask & 32);
   if (bf && d % 128 == 0 && !(generic_mask & 2))
     TR(TR_CONV1, launch_gemm_astat(melT, C, nullptr, nullptr, nullptr, nullptr, e->c1w, e->c1b, c1,
                                    (long)B * (Tin + 2), d, kConv1Kpad, EPI_CONV1, Tin + 2, s));
@@ -517,6 +520,25 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
       }
       qkv_done = false;
       if (i == 0 && skew_event) GWW_HIP(hipEventRecord(skew_event, s));   // the other half batch starts here
+      if (pooled && i == e->cfg.n_layers - 1) {
+        // ---- pooled forward: only token T-1 is wanted (Signal_vs_Noise/src/model.py:25-26) and everything above
+        // the last attention is row-wise.  Attention for the one query tile that holds token T-1, then out_proj /
+        // LN2 / fc1 / GELU / fc2 / final LayerNorm on the B last-token rows (xc is complete here: the QKV
+        // prologue folded the pending delta in).
+        TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s, nullptr, /*last_tile_only=*/true));
+        float* xl = xn;                        // [B, d] x rows (b, T-1)        (the ping-pong buffer is free now)
+        float* xm = xn + (size_t)B * d;        // [B, d] x_mid
+        float* xf = xn + 2 * (size_t)B * d;    // [B, d] layer output
+        GWW_HIP(hipMemcpy2DAsync(xl, (size_t)d * 4, xc + (size_t)(T - 1) * d, (size_t)T * d * 4, (size_t)d * 4, B,
+                                 hipMemcpyDeviceToDevice, s));
+        TR(TR_OUT, launch_gemm_bf16((const unsigned short*)ctx + (size_t)(T - 1) * d, (long)T * d, L.wo, L.bo, xl, nullptr,
+                                    xm, B, d, d, EPI_RESID, 0, s, 0));
+        TR(TR_LN, launch_layernorm(xm, L.ln2w, L.ln2b, d1, 1, B, d, s));
+        TR(TR_FC1, launch_gemm_bf16(d1, d, L.w1, L.b1, nullptr, nullptr, f1, B, F, d, EPI_GELU, 0, s, 0));
+        TR(TR_FC2, launch_gemm_bf16(f1, F, L.w2, L.b2, xm, nullptr, xf, B, d, F, EPI_RESID, 0, s, 0));
+        TR(TR_LN, launch_layernorm_rows(xf, d, e->lnw, e->lnb, last_token, B, d, s, nullptr));
+        return GWW_OK;
+      }
       TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s));
       TR(TR_OUT, launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, L.wo, L.bo, d1, M, d, d, EPI_BIAS, 0, s));
       if (mlp_fused && fuse_qkv && i + 1 < e->cfg.n_layers) {

@@ -209,6 +209,29 @@ def test_dual_stream_split_is_bit_identical(T, gww):
     assert T.equal(a_h, b_h) and T.equal(a_l, b_l)
 
 
+@pytest.mark.parametrize("name,B", [("tiny", 5), ("base", 2)])
+def test_pooled_forward_equals_last_row_of_full_forward(T, gww, name, B):
+    """``encoder.last_token`` (bf16): the last layer runs on the B last-token rows only (attention for the one
+    query tile holding token 1499, row-wise ops on B rows) -- the same function as ``last_hidden_state[:, -1]``
+    (reference ``src/model.py:25-26``), up to bf16 rounding of different GEMM tilings; also through the two-stream
+    split."""
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    sd = synth.named_encoder_state_dict(name, seed=2)
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig.named(name), precision="bf16").cuda()
+    mel = T.from_numpy(olm.log_mel(synth.strain_segments(B, seed=14))).cuda()
+    with T.no_grad():
+        hidden, last_full = enc.forward_raw(mel, want_hidden=True, want_last=True)
+        pooled = enc.last_token(mel)
+        enc.set_split(True)
+        pooled_split = enc.last_token(mel)
+        T.cuda.synchronize()
+    assert T.equal(last_full, hidden[:, -1])
+    err = (pooled - last_full).abs().max().item()
+    print(f"[{name}] max |pooled - full[:, -1]| = {err:.3e} (|x| max {last_full.abs().max().item():.2f})")
+    assert err < 0.06
+    assert (pooled_split - last_full).abs().max().item() < 0.06
+
+
 @pytest.mark.parametrize("name", ["base", "small"])
 def test_named_sizes_match_oracle(T, gww, name):
     """whisper-base (BASELINE config 4) and whisper-small (configs 3 and 5) geometry, one segment:
