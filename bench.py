@@ -207,6 +207,7 @@ def main():
     ap.add_argument("--split", type=int, default=0, help="0 (default): one stream; 1: two half batches on two HIP streams "
                     "(paid off before the fused MLP kernel, which owns a whole CU; now within noise)")
     ap.add_argument("--no-train", action="store_true", help="skip the DoRA step timing")
+    ap.add_argument("--no-pooled", action="store_true", help="skip the pooled (last-token-only) forward timing")
     ap.add_argument("--train-batch", type=int, default=32, help="per-GPU batch of the DoRA step (reference default 32)")
     ap.add_argument("--isolated", action="store_true", help="also time each kernel class in isolation")
     args = ap.parse_args()
@@ -285,8 +286,10 @@ def main():
     # extra (never `value`): the classifiers of the reference only read token 1499 (src/model.py:25-26); with
     # want_hidden=False the last layer runs on the B pooled rows above its attention.  Reported beside the full
     # forward, which stays the headline metric.
-    with torch.no_grad():
-        pooled_ms = time_kernel(lambda: enc.forward_raw(mel, want_hidden=False, want_last=True), iters=5, warm=2)
+    pooled_ms = None
+    if not args.no_pooled:
+        with torch.no_grad():
+            pooled_ms = time_kernel(lambda: enc.forward_raw(mel, want_hidden=False, want_last=True), iters=5, warm=2)
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -324,7 +327,8 @@ def main():
                                "config": f"{2 * B} x 2048 samples, qrange [4, 128], 148 tiles rows, 128 x 128 output"},
             "pooled_classify": {"what": "encoder.last_token(): same encoder, only last_hidden_state[:, -1] produced "
                                         "(last layer: one query tile of attention, row-wise ops on B rows)",
-                                "ms_per_batch": pooled_ms, "segments_per_s_per_gpu": B / pooled_ms * 1e3},
+                                "ms_per_batch": pooled_ms, "segments_per_s_per_gpu": B / pooled_ms * 1e3}
+            if pooled_ms else None,
             "dora_step_ms": train["ms"] if train else None,
             "dora_step": train,
         }

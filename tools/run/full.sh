@@ -1,6 +1,5 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -q -m gpu -x 2>&1 | grep -v "^$" > gpurun_out/t1.log; grep -n "FAILED\|passed\|failed\|rror" gpurun_out/t1.log | head -20
-timeout -k 10 600 python bench.py --no-cpu-baseline --no-train > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
-python tools/show_bench.py gpurun_out/bench.json
-GWW_GENERIC_PATH=16 timeout -k 10 600 python bench.py --no-cpu-baseline --no-train > gpurun_out/bench_nofuse.json 2> gpurun_out/bench_nofuse.err; python tools/show_bench.py gpurun_out/bench_nofuse.json
+timeout -k 10 1000 python -m pytest tests -q -m gpu -x > gpurun_out/t1.log 2>&1; rc=$?; tail -5 gpurun_out/t1.log; [ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; rc=$?; tail -4 gpurun_out/smoke.log; [ $rc -eq 0 ] || exit $rc
+bash tools/run/final.sh
