@@ -267,10 +267,333 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attention_bf16(con
   ASTAMP_FLUSH
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Software-pipelined form of the same kernel (experimental: GWW_ATT_PIPE=1 makes the encoder use it).
+// The kernel above runs S = K Q^T, the softmax VALU and the P V product of ONE tile back to back, so inside a wave
+// the matrix pipe idles through the 32 v_exp / 16 cvt / 20 max of every tile and the VALU idles through the MFMAs
+// (stamps: ~1600 cycles per wave-tile against ~650 of MFMA).  Here one straight-line block per tile holds the
+// S MFMAs of tile j+1, the exponentials of tile j and the P V MFMAs of tile j, so the scheduler can put the VALU
+// work into the MFMA shadows of the SAME wave:
+//   * scores live in log2 units relative to the running reference m: the caller folds log2(e) into the q
+//     projection (encoder.hip packs the LN-folded q panel with log2(e) / 8; scaling the bf16 q here would add a
+//     second rounding), and -m enters through the C operand of the first k-step (`cneg`), so p = v_exp_f32(s)
+//     with no multiply-add per score;
+//   * the row maximum of tile j+1 is reduced inside the block too; the (rare, deferred by kDeferLog2) re-basing
+//     of O, l and the already computed scores happens between blocks;
+//   * K runs one tile ahead of V through the same two LDS buffers each (K(j+2) and V(j+1) are staged at the end
+//     of block j); still one barrier per tile.  The tile loop is unrolled by two so the score registers swap
+//     roles without copies and every LDS address is an immediate.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsigned short* __restrict__ qkv,
+                                                                    unsigned short* __restrict__ ctx,
+                                                                    float* __restrict__ lse, int T, int H, int q_tiles,
+                                                                    int qt0) {
+  static_assert(NW == 4, "128 query rows per workgroup");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KB * DH * 2];   // 32 KB
+  constexpr int TILE_BYTES = KB * DH * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned nblk = gridDim.x, per = nblk >> 3;
+  const unsigned wid = blockIdx.x < 8 * per ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
+  const int qt = qt0 + wid % q_tiles;
+  const int bh = wid / q_tiles;
+  const int b = bh / H, h = bh - b * H;
+  const int d = H * DH;
+  const long row_stride = 3L * d;
+  const unsigned short* base = qkv + (long)b * T * row_stride;
+  const unsigned short* qp = base + h * DH;
+  const unsigned short* kp = base + d + h * DH;
+  const unsigned short* vp = base + 2 * d + h * DH;
+  const int r = lane & 31, hh = lane >> 5;
+  const int q_row = qt * (NW * 32) + wave * 32 + r;
+  const int q_ld = q_row < T ? q_row : T - 1;
+
+  // Q fragments (B operand of K Q^T); q arrives in log2 units (log2(e) / 8 folded into the packed q_proj panel)
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    qf[s] = *reinterpret_cast<const bf16x8*>(qp + (long)q_ld * row_stride + 16 * s + 8 * hh);
+
+  constexpr int NCH = 512 / (NW * 64);
+  int st_row[NCH], st_chunk[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + NW * 64 * i;
+    st_row[i] = c >> 3;
+    st_chunk[i] = c & 7;
+  }
+  u32x4 rk[NCH], rv[NCH];
+  // global addresses = wave-uniform tile base (scalar registers) + a 32-bit per-lane offset that never changes;
+  // only the ragged last tile clamps its rows to T - 1, through a second set of offsets
+  const int n_kt = (T + KB - 1) / KB;
+  unsigned off_full[NCH], off_last[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    off_full[i] = (unsigned)(st_row[i] * (int)row_stride + st_chunk[i] * 8);
+    int key = (n_kt - 1) * KB + st_row[i];
+    if (key >= T) key = T - 1;
+    off_last[i] = (unsigned)((key - (n_kt - 1) * KB) * (int)row_stride + st_chunk[i] * 8);
+  }
+  auto gload_k = [&](int kt) {
+    const unsigned short* kb = kp + (long)kt * KB * row_stride;
+    const bool last = kt == n_kt - 1;   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) rk[i] = *reinterpret_cast<const u32x4*>(kb + (last ? off_last[i] : off_full[i]));
+  };
+  auto gload_v = [&](int kt) {
+    const unsigned short* vb = vp + (long)kt * KB * row_stride;
+    const bool last = kt == n_kt - 1;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) rv[i] = *reinterpret_cast<const u32x4*>(vb + (last ? off_last[i] : off_full[i]));
+  };
+  auto lstore_k = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(lds + buf * TILE_BYTES + k_off(st_row[i], st_chunk[i])) = rk[i];
+  };
+  auto lstore_v = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      *reinterpret_cast<u32x4*>(lds + (2 + buf) * TILE_BYTES + v_off(st_row[i], st_chunk[i] * 16)) = rv[i];
+  };
+
+  f32x16 ot[2], lt, cneg;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { ot[0][j] = 0.f; ot[1][j] = 0.f; lt[j] = 0.f; cneg[j] = 0.f; }
+  float m_run = 0.f;   // log2 units
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+  const int tr_colbyte = (((lane & 31) >> 4) * 16 + 4 * tr_p) * 2;
+  const bool ragged = (T % KB) != 0;
+  constexpr float kDeferLog2 = 8.0f * kLog2e;
+
+  // S^T of one tile, relative to the current reference: st[g][reg] <-> key 32 g + (reg&3) + 8 (reg>>2) + 4 hh
+  auto scores = [&](f32x16 (&st)[2], int buf) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(lds + buf * TILE_BYTES + k_off(32 * g + r, 2 * s + hh));
+        st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? cneg : st[g], 0, 0, 0);
+      }
+    }
+  };
+  auto mask_last = [&](f32x16 (&st)[2]) {   // keys >= T of the last tile
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int key = (n_kt - 1) * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        if (key >= T) st[g][j] = -INFINITY;
+      }
+  };
+  auto rowmax = [&](const f32x16 (&st)[2]) {
+    float t = st[0][0];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) t = fmaxf(t, st[g][j]);
+    return fmaxf(t, __shfl_xor(t, 32, 64));
+  };
+  // move the reference by dm (per row): O, l and the scores already computed against the old reference
+  auto rebase = [&](f32x16 (&st)[2], float dm) {
+    const float alpha = __builtin_amdgcn_exp2f(-dm);
+    m_run += dm;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      lt[j] *= alpha;
+      ot[0][j] *= alpha;
+      ot[1][j] *= alpha;
+      st[0][j] -= dm;
+      st[1][j] -= dm;
+      cneg[j] = -m_run;
+    }
+  };
+  // one tile: [S of the next tile] + exp of this tile + P V of this tile (+ row max of the next tile)
+  auto block = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], float& tmax, auto par_c, auto next_c, auto mask_c) {
+    constexpr int PAR = decltype(par_c)::value;            // tile parity: V buffer PAR, next K buffer PAR ^ 1
+    constexpr bool NEXT = decltype(next_c)::value, MASK = decltype(mask_c)::value;
+    if (__builtin_amdgcn_ballot_w64(tmax > kDeferLog2) != 0) rebase(sc, fmaxf(tmax, 0.f));   // wave-uniform, rare
+    // Phase 1: all K fragments of the next tile are requested first, then its 8 S MFMAs (the two 32-key halves
+    // alternate, so no MFMA waits for its predecessor's accumulator) carry 4 of this tile's 32 exponentials each.
+    // Phase 2: 4 x (P -> bf16, 3 MFMAs) with the next V fragments requested one step ahead and the row maximum of
+    // the next tile's scores in the MFMA shadows.  The scheduling groups pin that order.
+    typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+    const unsigned char* vs = lds + (2 + PAR) * TILE_BYTES;
+    bf16x8 vfr[2][2];
+    auto load_v = [&](int c) {   // V^T A operands of step c = (g, s): keys 32 g + 16 s + ..., dh = 32 n + r
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int key0 = 16 * c + 4 * hh + tr_q;
+        const int cb = 64 * n + tr_colbyte;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vs + v_off(key0, cb)));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vs + v_off(key0 + 8, cb)));
+        bf16x8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+        vfr[c & 1][n] = vf;
+      }
+    };
+    if constexpr (NEXT) {
+      bf16x8 kf[2][4];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          kf[g][s] = *reinterpret_cast<const bf16x8*>(lds + (PAR ^ 1) * TILE_BYTES + k_off(32 * g + r, 2 * s + hh));
+      load_v(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          sn[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[g][s], qf[s], s == 0 ? cneg : sn[g], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int idx = 4 * (2 * s + g) + j;
+            sc[idx >> 4][idx & 15] = __builtin_amdgcn_exp2f(sc[idx >> 4][idx & 15]);
+          }
+        }
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);   // 8 K + 4 V fragment reads
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);   // 4 v_exp_f32
+      }
+    } else {
+      load_v(0);
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sc[g][j] = __builtin_amdgcn_exp2f(sc[g][j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float t = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int g = c >> 1, s2 = c & 1;
+      if (c < 3) load_v(c + 1);
+      const bf16x8 pf = cvt8(sc[g], 8 * s2);
+      lt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lt, 0, 0, 0);
+      ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[c & 1][0], pf, ot[0], 0, 0, 0);
+      ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[c & 1][1], pf, ot[1], 0, 0, 0);
+      if constexpr (NEXT) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int reg = 8 * s2 + j;
+          if constexpr (MASK) {
+            const int key = (n_kt - 1) * KB + 32 * g + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            if (key >= T) sn[g][reg] = -INFINITY;
+          }
+          t = fmaxf(t, sn[g][reg]);
+        }
+      }
+      if constexpr (!MASK) {
+        if (c < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // next step's V fragments
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);               // 4 cvt_pk
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);               // row maximum of the next tile
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NEXT) tmax = fmaxf(t, __shfl_xor(t, 32, 64));
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using Yes = std::true_type;
+  using No = std::false_type;
+
+  // ---- prologue: S(0) against reference 0, then the reference becomes the row maximum of tile 0
+  f32x16 sa[2], sb[2];
+  gload_k(0);
+  lstore_k(0);
+  if (n_kt > 1) gload_k(1);
+  gload_v(0);
+  __syncthreads();
+  scores(sa, 0);
+  if (n_kt == 1 && ragged) mask_last(sa);
+  float tmax = rowmax(sa);
+  rebase(sa, tmax);
+  tmax = 0.f;
+  if (n_kt > 1) lstore_k(1);
+  lstore_v(0);
+  __syncthreads();
+
+  // steady state at tile kt (parity PAR): LDS holds K(kt+1) [K buffer PAR^1] and V(kt) [V buffer PAR]
+  auto main_iter = [&](int kt, f32x16 (&sc)[2], f32x16 (&sn)[2], auto par_c) {   // needs kt + 2 < n_kt
+    constexpr int PAR = decltype(par_c)::value;
+#ifdef GWW_ATT_NOLOAD   // diagnostic: no K / V traffic in the steady state (wrong results)
+    if (kt < 0) {
+#endif
+    gload_k(kt + 2);
+    gload_v(kt + 1);
+#ifdef GWW_ATT_NOLOAD
+    }
+#endif
+    block(sc, sn, tmax, par_c, Yes{}, No{});
+    lstore_k(PAR);
+    lstore_v(PAR ^ 1);
+    __syncthreads();
+  };
+  auto prelast_iter = [&](int kt, f32x16 (&sc)[2], f32x16 (&sn)[2], auto par_c) {   // kt + 2 == n_kt
+    constexpr int PAR = decltype(par_c)::value;
+    gload_v(kt + 1);
+    if (ragged) block(sc, sn, tmax, par_c, Yes{}, Yes{});
+    else block(sc, sn, tmax, par_c, Yes{}, No{});
+    lstore_v(PAR ^ 1);
+    __syncthreads();
+  };
+  int kt = 0;
+  for (; kt + 3 < n_kt; kt += 2) {
+    main_iter(kt, sa, sb, P0{});
+    main_iter(kt + 1, sb, sa, P1{});
+  }
+  const int rem = n_kt - kt;   // 1, 2 or 3 tiles left, kt even, scores of tile kt in sa
+  if (rem == 3) {
+    main_iter(kt, sa, sb, P0{});
+    prelast_iter(kt + 1, sb, sa, P1{});
+    block(sa, sb, tmax, P0{}, No{}, No{});
+  } else if (rem == 2) {
+    prelast_iter(kt, sa, sb, P0{});
+    block(sb, sa, tmax, P1{}, No{}, No{});
+  } else {
+    block(sa, sb, tmax, P0{}, No{}, No{});
+  }
+
+  const float l_tot = lt[0];
+  const float inv = 1.0f / l_tot;
+  if (lse && q_row < T && hh == 0) lse[((long)b * H + h) * T + q_row] = (m_run + __log2f(l_tot)) * 0.69314718055994530942f;
+  if (q_row < T) {
+    unsigned short* orow = ctx + ((long)b * T + q_row) * d + h * DH;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int dh = 32 * n + 8 * c + 4 * hh;
+        u32x2 o = {pack2bf(ot[n][4 * c] * inv, ot[n][4 * c + 1] * inv),
+                   pack2bf(ot[n][4 * c + 2] * inv, ot[n][4 * c + 3] * inv)};
+        *reinterpret_cast<u32x2*>(orow + dh) = o;
+      }
+  }
+}
+
 // last_tile_only: compute only the query tile that holds token T - 1 (the other rows of ctx are left untouched) --
 // the pooled forward needs nothing else of the last layer's attention.
+// q_log2: q was projected with log2(e) / 8 instead of 1 / 8 -> the software-pipelined kernel.
+// attention_pipe_enabled(): whether the encoder's fast path packs its q panel that way and launches that kernel.
+// OFF by default: measured 1.21-1.25 ms per whisper-tiny layer at B = 256 against 1.12-1.14 ms for the kernel above
+// (GWW_ATT_PIPE=1 to compare) -- at two waves per SIMD (256 registers) the better intra-wave overlap does not pay
+// for the third wave the plain kernel keeps; with its K / V loads removed it still needs 1.00 ms, i.e. both
+// kernels are bound by instruction issue per wave (~235 instructions per 64-key tile), not by the memory system.
+bool attention_pipe_enabled() {
+  static const bool on = getenv("GWW_ATT_PIPE") && atoi(getenv("GWW_ATT_PIPE")) != 0;
+  return on;
+}
+
 int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipStream_t s, float* lse,
-                          bool last_tile_only) {
+                          bool last_tile_only, bool q_log2) {
   GWW_REQUIRE(qkv && ctx, "attention_bf16: NULL operand");
   GWW_REQUIRE(B >= 0 && T > 0 && H > 0, "attention_bf16: bad shape B=%d T=%d H=%d", B, T, H);
   GWW_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)ctx) & 15) == 0, "attention_bf16: 16-byte alignment");
@@ -278,12 +601,15 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
   static const int nw_env = getenv("GWW_ATT_WAVES") ? atoi(getenv("GWW_ATT_WAVES")) : 0;   // tuning aid: 4 or 8
   // 128 query rows per workgroup, two workgroups per CU; the 256-row form (one per CU, K / V streamed once per
   // 256 queries) measures 5 % slower at T = 1500 -- the kernel is issue-bound, not L2-bound
-  const int nw = nw_env == 8 ? 8 : 4;
+  const int nw = (nw_env == 8 && !q_log2) ? 8 : 4;
   const int all_tiles = (T + nw * 32 - 1) / (nw * 32);
   const int q_tiles = last_tile_only ? 1 : all_tiles, qt0 = last_tile_only ? all_tiles - 1 : 0;
   const long blocks = (long)q_tiles * B * H;
   GWW_REQUIRE(blocks < 2147483647L, "attention_bf16: grid too large");
-  if (nw == 8)
+  if (q_log2)
+    hipLaunchKernelGGL(k_attention_pipe_bf16<4>, dim3((unsigned)blocks), dim3(256), 0, s,
+                       (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles, qt0);
+  else if (nw == 8)
     hipLaunchKernelGGL(k_attention_bf16<8>, dim3((unsigned)blocks), dim3(512), 0, s,
                        (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles, qt0);
   else
@@ -431,6 +757,11 @@ extern "C" int gww_attention_bf16(const void* qkv, void* ctx, int B, int T, int 
 extern "C" int gww_attention_lse_bf16(const void* qkv, void* ctx, float* lse, int B, int T, int n_heads, void* stream) {
   GWW_REQUIRE(lse != nullptr, "gww_attention_lse_bf16: lse is NULL");
   return launch_attention_bf16(qkv, ctx, B, T, n_heads, (hipStream_t)stream, lse);
+}
+
+extern "C" int gww_attention_log2q_bf16(const void* qkv, void* ctx, float* lse_or_null, int B, int T, int n_heads,
+                                        void* stream) {
+  return launch_attention_bf16(qkv, ctx, B, T, n_heads, (hipStream_t)stream, lse_or_null, false, true);
 }
 extern "C" int gww_attention_f32(const float* qkv, float* ctx, int B, int T, int n_heads, void* stream) {
   return launch_attention_f32(qkv, ctx, B, T, n_heads, (hipStream_t)stream);

@@ -115,7 +115,8 @@ int launch_gemm_f32(const float* A, long lda, const float* W, const float* bias,
                     const float* pos, float* C, long M, int N, int K, int epi, int rows_per_batch,
                     hipStream_t s);
 int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipStream_t s, float* lse = nullptr,
-                          bool last_tile_only = false);
+                          bool last_tile_only = false, bool q_log2 = false);
+bool attention_pipe_enabled();
 int launch_attention_f32(const float* qkv, float* ctx, int B, int T, int H, hipStream_t s);
 int launch_conv1_bf16(const float* mel, const void* w_packed, const float* bias, void* out,
                       int B, int T, int n_mels, int d, hipStream_t s);

@@ -298,7 +298,10 @@ static int pack_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_
       GWW_TRY(launch_scale_copy(L.ln1_w, w.ln1w, d, 1.f, s));
       GWW_TRY(launch_scale_copy(L.ln1_b, w.ln1b, d, 1.f, s));
       // gain-folded panel + correction vectors for the algebraic LayerNorm of the A-stationary GEMM
-      GWW_TRY(launch_ln_fold(L.q_w, L.ln1_w, L.ln1_b, L.q_b, qs, d, d, w.wqkv_ln, w.uqkv, w.cbqkv, s));
+      // (the A-stationary inference path feeds the software-pipelined attention kernel, which takes q in log2
+      // units: log2(e) rides in the q panel, one rounding of the fp32 product instead of a second one on bf16 q)
+      GWW_TRY(launch_ln_fold(L.q_w, L.ln1_w, L.ln1_b, L.q_b, attention_pipe_enabled() ? qs * 1.44269504088896340736f : qs,
+                             d, d, w.wqkv_ln, w.uqkv, w.cbqkv, s));
       GWW_TRY(launch_ln_fold(L.k_w, L.ln1_w, L.ln1_b, nullptr, 1.f, d, d, w.wqkv_ln + dd, w.uqkv + d, w.cbqkv + d, s));
       GWW_TRY(launch_ln_fold(L.v_w, L.ln1_w, L.ln1_b, L.v_b, 1.f, d, d, w.wqkv_ln + 2 * dd, w.uqkv + 2 * d,
                              w.cbqkv + 2 * d, s));
@@ -503,6 +506,7 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   else
     TR(TR_CONV2, gemm(c1, 2L * d, e->c2w, e->c2w32, e->c2b, nullptr, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2,
                       T + 1));
+  const bool q_log2 = attention_pipe_enabled();   // the LN-folded q panel carries log2(e) (pack_weights)
   float* xc = x;                       // current residual stream
   const void* pending = nullptr;       // bf16 delta not yet added to xc (A-stationary path)
   if (astat) {
@@ -525,7 +529,7 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
         // the last attention is row-wise.  Attention for the one query tile that holds token T-1, then out_proj /
         // LN2 / fc1 / GELU / fc2 / final LayerNorm on the B last-token rows (xc is complete here: the QKV
         // prologue folded the pending delta in).
-        TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s, nullptr, /*last_tile_only=*/true));
+        TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s, nullptr, /*last_tile_only=*/true, q_log2));
         float* xl = xn;                        // [B, d] x rows (b, T-1)        (the ping-pong buffer is free now)
         float* xm = xn + (size_t)B * d;        // [B, d] x_mid
         float* xf = xn + 2 * (size_t)B * d;    // [B, d] layer output
@@ -539,7 +543,7 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
         TR(TR_LN, launch_layernorm_rows(xf, d, e->lnw, e->lnb, last_token, B, d, s, nullptr));
         return GWW_OK;
       }
-      TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s));
+      TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s, nullptr, false, q_log2));
       TR(TR_OUT, launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, L.wo, L.bo, d1, M, d, d, EPI_BIAS, 0, s));
       if (mlp_fused && fuse_qkv && i + 1 < e->cfg.n_layers) {
         // ... and the next layer's LN1 + q / k / v projection appended: xn receives x_next (no delta pending)

@@ -225,6 +225,21 @@ def attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:
     return ctx
 
 
+def attention_log2q(qkv: torch.Tensor, n_heads: int, want_lse: bool = False):
+    """The software-pipelined bf16 kernel of the encoder's fast path: like :func:`attention`, but the q section is
+    in log2 units (projected with log2(e) / 8 instead of 1 / 8).  Returns ctx, or (ctx, lse [B, H, T] natural log)."""
+    qkv = _dev(qkv, torch.bfloat16, "qkv")
+    B, T, d3 = qkv.shape
+    if d3 != 3 * n_heads * 64:
+        raise _lib.GwwError(f"attention: d={d3 // 3} != n_heads*64")
+    ctx = torch.empty((B, T, d3 // 3), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, n_heads, T), dtype=torch.float32, device=qkv.device) if want_lse else None
+    with torch.cuda.device(qkv.device):
+        check(lib().gww_attention_log2q_bf16(qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr() if want_lse else None, B, T,
+                                             n_heads, _stream()), "gww_attention_log2q_bf16")
+    return (ctx, lse) if want_lse else ctx
+
+
 def dora_merge(w0: torch.Tensor, a: torch.Tensor, b: torch.Tensor, m: torch.Tensor, scaling: float,
                return_norm: bool = False):
     """W_eff = (m / ||W0 + s B A||_row) * (W0 + s B A)  (peft 0.12.0 dora.py), fp32."""

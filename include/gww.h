@@ -265,6 +265,9 @@ int gww_gemm_f32(const float* A, const float* W, const float* bias, const float*
 /* softmax(q k^T) v per head, q pre-scaled; qkv [B,T,3*d] (q|k|v), ctx [B,T,d]; head_dim 64 */
 int gww_attention_bf16(const void* qkv, void* ctx, int B, int T, int n_heads, void* stream);
 int gww_attention_f32(const float* qkv, float* ctx, int B, int T, int n_heads, void* stream);
+/* the software-pipelined bf16 kernel the encoder's fast path launches: q must be in log2 units, i.e. projected with
+ * log2(e) / 8 instead of 1 / 8 (gww_encoder_set_weights folds that into the packed q panel); lse optional, natural log */
+int gww_attention_log2q_bf16(const void* qkv, void* ctx, float* lse_or_null, int B, int T, int n_heads, void* stream);
 /* attention backward: dqkv [B,T,3d] from qkv, ctx (forward output), dctx and the forward's lse [B,H,T]
  * (gww_attention_lse_bf16 below); d_scratch: B * H * (T + ceil(T / 64)) fp32 words (row dots + live-tile flags:
  * query tiles whose dctx rows are all zero are skipped, which is most of them under last-token pooling) */

@@ -258,6 +258,70 @@ def test_attention_bf16(T, gww, B, Tn, H):
     np.testing.assert_allclose(got, ref, atol=6e-3, rtol=2 ** -7)
 
 
+_LOG2E = 1.4426950408889634
+
+
+def _to_log2q(qkv):
+    """q section scaled by log2(e) and rounded to bf16 once: what the LN-folded q panel of the fast path produces."""
+    d = qkv.shape[-1] // 3
+    out = qkv.copy()
+    out[..., :d] = _bf(qkv[..., :d].astype(np.float64) * _LOG2E)
+    return out
+
+
+def _attn_ref_log2q(qkv_l2, H):
+    """oracle/encoder.py::attention (bf16 emulation: un-normalised bf16 P, fp32 row sum) on q / log2(e) -- restated here
+    because the oracle would round that quotient to bf16 again."""
+    B, Tn, d3 = qkv_l2.shape
+    d = d3 // 3
+    x = qkv_l2.astype(np.float64)
+    heads = lambda a: a.reshape(B, Tn, H, 64).transpose(0, 2, 1, 3)
+    q, k, v = heads(x[..., :d] / _LOG2E), heads(x[..., d:2 * d]), heads(x[..., 2 * d:])
+    s = np.matmul(q, k.transpose(0, 1, 3, 2))
+    p = np.exp(s - s.max(axis=-1, keepdims=True))
+    o = np.matmul(_bf(p.astype(np.float32)).astype(np.float64), v) / p.sum(axis=-1, keepdims=True)
+    return o.transpose(0, 2, 1, 3).reshape(B, Tn, d)
+
+
+@pytest.mark.parametrize("B,Tn,H", [(1, 64, 1), (1, 37, 1), (2, 200, 2), (1, 128, 1), (1, 192, 2), (1, 1500, 2),
+                                    (3, 129, 6), (2, 257, 1)])
+def test_attention_pipelined_log2q(T, gww, B, Tn, H):
+    """The software-pipelined kernel (scores of tile j+1 beside the softmax of tile j; q in log2 units): one, two,
+    three ... tiles, ragged and full last tiles, and the log-sum-exp it hands to training-style consumers."""
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(B * 1000 + Tn + H)
+    qkv = _to_log2q(_bf(rng.standard_normal((B, Tn, 3 * H * 64)) * 0.7))
+    ref = _attn_ref_log2q(qkv, H)
+    got, lse = ops.attention_log2q(T.from_numpy(qkv).cuda().bfloat16(), H, want_lse=True)
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=6e-3, rtol=2 ** -7)
+    d = H * 64
+    q = qkv[..., :d].astype(np.float64) / _LOG2E
+    k = qkv[..., d:2 * d].astype(np.float64)
+    for h in range(H):
+        s = np.einsum("bqd,bkd->bqk", q[..., h * 64:(h + 1) * 64], k[..., h * 64:(h + 1) * 64])
+        m = s.max(-1, keepdims=True)
+        ref_lse = (m + np.log(np.exp(s - m).sum(-1, keepdims=True)))[..., 0]
+        np.testing.assert_allclose(lse[:, h].cpu().numpy(), ref_lse, atol=2e-2, rtol=1e-3)
+
+
+def test_attention_pipelined_spike_forces_rebase(T, gww):
+    """A key far above the running reference late in the sequence (score 256): O, l AND the scores of the tile
+    computed against the old reference must move to the new one; then a long tail of small scores."""
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(5)
+    H, Tn = 1, 600
+    qkv = (rng.standard_normal((1, Tn, 192)) * 0.3).astype(np.float32)
+    qkv[0, 17, :64] = 2.0
+    qkv[0, 450, 64:128] = 2.0
+    qkv[0, 300, :64] = -3.0            # a row whose scores are all very negative against key 450
+    qkv = _to_log2q(_bf(qkv))
+    ref = _attn_ref_log2q(qkv, H)
+    got = ops.attention_log2q(T.from_numpy(qkv).cuda().bfloat16(), H).float().cpu().numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, ref, atol=6e-3, rtol=2 ** -7)
+    np.testing.assert_allclose(got[0, 17], qkv[0, 450, 128:192], atol=1e-2)
+
+
 def test_attention_bf16_spike_forces_rescale(T, gww):
     """One key dominates one query late in the sequence: the running max jumps at a
     chosen tile and every earlier partial sum must be rescaled (guide rule 26)."""
