@@ -420,7 +420,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
     // the next tile's scores in the MFMA shadows.  The scheduling groups pin that order.
     typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
     const unsigned char* vs = lds + (2 + PAR) * TILE_BYTES;
-    bf16x8 vfr[2][2];
+    bf16x8 vfr[4][2];
     auto load_v = [&](int c) {   // V^T A operands of step c = (g, s): keys 32 g + 16 s + ..., dh = 32 n + r
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
         bf16x8 vf;
         vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
         vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-        vfr[c & 1][n] = vf;
+        vfr[c][n] = vf;
       }
     };
     if constexpr (NEXT) {
@@ -442,6 +442,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
         for (int s = 0; s < 4; ++s)
           kf[g][s] = *reinterpret_cast<const bf16x8*>(lds + (PAR ^ 1) * TILE_BYTES + k_off(32 * g + r, 2 * s + hh));
       load_v(0);
+      load_v(1);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
             sc[idx >> 4][idx & 15] = __builtin_amdgcn_exp2f(sc[idx >> 4][idx & 15]);
           }
         }
-      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);   // 8 K + 4 V fragment reads
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // 8 K + 8 V fragment reads (steps 0 and 1 of phase 2)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
@@ -461,21 +462,23 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
       }
     } else {
       load_v(0);
+      load_v(1);
 #pragma unroll
       for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int j = 0; j < 16; ++j) sc[g][j] = __builtin_amdgcn_exp2f(sc[g][j]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    load_v(2);   // the second half's V fragments: two steps (6 MFMAs) ahead of their use
+    load_v(3);
     float t = -INFINITY;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int g = c >> 1, s2 = c & 1;
-      if (c < 3) load_v(c + 1);
       const bf16x8 pf = cvt8(sc[g], 8 * s2);
       lt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lt, 0, 0, 0);
-      ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[c & 1][0], pf, ot[0], 0, 0, 0);
-      ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[c & 1][1], pf, ot[1], 0, 0, 0);
+      ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[c][0], pf, ot[0], 0, 0, 0);
+      ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[c][1], pf, ot[1], 0, 0, 0);
       if constexpr (NEXT) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
         }
       }
       if constexpr (!MASK) {
-        if (c < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // next step's V fragments
+        if (c == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // V fragments of steps 2 and 3
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);               // 4 cvt_pk
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);               // row maximum of the next tile
