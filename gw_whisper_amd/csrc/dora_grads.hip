@@ -71,13 +71,16 @@ __device__ __forceinline__ float bf_lo(unsigned int w) { return __uint_as_float(
 __device__ __forceinline__ float bf_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
 }  // namespace
 
-template <int D, int NP>
+// WLDS: the phase-A weights live in LDS instead of registers (d = 768: 192 registers of weights beside 192 of
+// accumulators would spill)
+template <int D, int NP, bool WLDS = false>
 __global__ __launch_bounds__(256) void k_dora_grads_mfma(const unsigned short* __restrict__ X, long ldx,
                                                          const unsigned short* __restrict__ dY,
                                                          const unsigned short* __restrict__ Y, long ldy,
                                                          const DoraProjs pr, long M, float* __restrict__ scratch) {
   constexpr int R = 32, CH = D / 8, IMG = R * D * 2, KS = D / 16, JB = D / 128;
-  static_assert(D % 128 == 0 && 4 * CH <= 256 && NP >= 1 && NP <= 3, "shape");
+  constexpr int RP = D <= 512 ? 4 : 2;   // staging row phases: RP * CH threads load, each its chunk of R / RP rows
+  static_assert(D % 128 == 0 && RP * CH <= 256 && NP >= 1 && NP <= 3, "shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* Us = lds + (1 + NP) * IMG;   // [32 n][32 rows] bf16
   unsigned char* Vs = Us + 2048;
@@ -85,37 +88,52 @@ __global__ __launch_bounds__(256) void k_dora_grads_mfma(const unsigned short* _
   const int n = lane & 31, hh = lane >> 5;
 
   // ---- phase-A weights of this wave as B operands: lane (n, hh), k-step s holds W[k = 16 s + 8 hh + j][n]
-  bf16x8 wf[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wf[s][j] = (__bf16)0.f;
-  if (wave == 0) {
-    if (n < 8 * NP) {
-      const float* a = pr.p[n >> 3].A + (long)(n & 7) * D + 8 * hh;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(a + 16 * s), hi = *reinterpret_cast<const f32x4*>(a + 16 * s + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { wf[s][j] = (__bf16)lo[j]; wf[s][4 + j] = (__bf16)hi[j]; }
-      }
+  constexpr int WROW = D * 2 + 16;              // LDS weight row (bytes), padded against bank conflicts
+  unsigned char* Wl = Vs + 2048;                // WLDS: [8 NP rows of A_all | NP x 8 rows of (g . B)^T], bf16 [row][k]
+  bf16x8 wf[WLDS ? 1 : KS];
+  const bool w_lane = wave == 0 ? n < 8 * NP : (n >> 3) == wave - 1;          // lanes with a non-zero weight column
+  const int w_row = wave == 0 ? (n < 8 * NP ? n : 0) : 8 * NP + 8 * (wave - 1) + (n & 7);
+  if constexpr (WLDS) {
+    for (int i = tid; i < 8 * NP * D; i += 256) {
+      const int row = i / D, k = i - row * D;
+      const DoraProj& P = pr.p[row >> 3];
+      const int r = row & 7;
+      *reinterpret_cast<__bf16*>(Wl + row * WROW + 2 * k) = (__bf16)P.A[(long)r * D + k];
+      *reinterpret_cast<__bf16*>(Wl + (8 * NP + row) * WROW + 2 * k) =
+          (__bf16)(P.yscale * (P.mag[k] / P.nrm[k]) * P.Bm[(long)k * 8 + r]);
     }
-  } else if (wave <= NP) {
-    const DoraProj& P = pr.p[wave - 1];
-    if ((n >> 3) == wave - 1) {
-      const int r = n & 7;
+  } else {
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = 16 * s + 8 * hh + j;
-          wf[s][j] = (__bf16)(P.yscale * (P.mag[k] / P.nrm[k]) * P.Bm[(long)k * 8 + r]);
+      for (int j = 0; j < 8; ++j) wf[s][j] = (__bf16)0.f;
+    if (wave == 0) {
+      if (n < 8 * NP) {
+        const float* a = pr.p[n >> 3].A + (long)(n & 7) * D + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(a + 16 * s), hi = *reinterpret_cast<const f32x4*>(a + 16 * s + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { wf[s][j] = (__bf16)lo[j]; wf[s][4 + j] = (__bf16)hi[j]; }
         }
+      }
+    } else if (wave <= NP) {
+      const DoraProj& P = pr.p[wave - 1];
+      if ((n >> 3) == wave - 1) {
+        const int r = n & 7;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = 16 * s + 8 * hh + j;
+            wf[s][j] = (__bf16)(P.yscale * (P.mag[k] / P.nrm[k]) * P.Bm[(long)k * 8 + r]);
+          }
+      }
     }
   }
 
-  // ---- staging role: 16-byte chunk c8 of rows ph, ph + 4, ... (threads past 4 CH idle: D = 384 -> wave 3)
-  const bool stager = tid < 4 * CH;
+  // ---- staging role: 16-byte chunk c8 of rows ph, ph + RP, ... (threads past RP CH idle: D = 384, 768 -> wave 3)
+  const bool stager = tid < RP * CH;
   const int c8 = tid % CH, ph = tid / CH;
   const int st_sub = (c8 >> 4) * (32 * 256), st_ch = c8 & 15;
   float dyy[NP][8];
@@ -147,11 +165,11 @@ __global__ __launch_bounds__(256) void k_dora_grads_mfma(const unsigned short* _
     if (stager) {
       // 2 rows per trip and no unrolling: the compiler would otherwise hoist all 8 rows' loads (7 x 32 registers)
 #pragma unroll 1
-      for (int qq = 0; qq < 4; ++qq) {
+      for (int qq = 0; qq < R / RP / 2; ++qq) {
         u32x4 vx[2], vd[NP][2], vy[NP][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const long row = r0 + 4 * (2 * qq + i) + ph;
+          const long row = r0 + RP * (2 * qq + i) + ph;
           const bool ok = row < M;
           vx[i] = ok ? *reinterpret_cast<const u32x4*>(X + row * ldx + 8 * c8) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(256) void k_dora_grads_mfma(const unsigned short* _
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int row = 4 * (2 * qq + i) + ph;
+          const int row = RP * (2 * qq + i) + ph;
           const int off = st_sub + dual_off(row, st_ch);
           *reinterpret_cast<u32x4*>(lds + off) = vx[i];
 #pragma unroll
@@ -188,7 +206,13 @@ __global__ __launch_bounds__(256) void k_dora_grads_mfma(const unsigned short* _
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(img + (s >> 3) * (32 * 256) + dual_off(n, 2 * (s & 7) + hh));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wf[s], acc, 0, 0, 0);
+        if constexpr (WLDS) {
+          u32x4 wv = *reinterpret_cast<const u32x4*>(Wl + w_row * WROW + (16 * s + 8 * hh) * 2);
+          if (!w_lane) wv = u32x4{0u, 0u, 0u, 0u};
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, wv), acc, 0, 0, 0);
+        } else {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wf[s], acc, 0, 0, 0);
+        }
       }
       // acc[4 c + e] = out[row 8 c + 4 hh + e][n]  ->  [n][row] bf16
       if (wave == 0 || (n >> 3) == wave - 1) {
@@ -237,8 +261,8 @@ __global__ __launch_bounds__(256) void k_dora_grads_mfma(const unsigned short* _
   // ---------------- epilogue: acc[4 c + e] = out[column 32 jb + 8 c + 4 hh + e][n].  Every workgroup leaves its
   // partial sums in its own slab of `scratch` (plain 16-byte stores); k_dora_reduce adds the slabs up.  (fp32
   // atomics straight into dA / dB / dm cost ~300 us per call: 6 M device-scope atomics on 20 k addresses.)
-  //   slab: PA [NP][8][D] | PB [NP][8][D] | PS [NP][D] | PY [NP][4][D]
-  float* slab = scratch + (long)blockIdx.x * (NP * D * 21);
+  //   slab: PA [NP][8][D] | PB [NP][8][D] | PS [NP][D] | PY [NP][RP][D]
+  float* slab = scratch + (long)blockIdx.x * (NP * D * (17 + RP));
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     if (own[p] || n == 24 + p) {
@@ -259,7 +283,7 @@ __global__ __launch_bounds__(256) void k_dora_grads_mfma(const unsigned short* _
         }
     }
     if (stager) {
-      float* py = slab + 2 * NP * 8 * D + NP * D + (p * 4 + ph) * D + 8 * c8;
+      float* py = slab + 2 * NP * 8 * D + NP * D + (p * RP + ph) * D + 8 * c8;
       *reinterpret_cast<f32x4*>(py) = f32x4{dyy[p][0], dyy[p][1], dyy[p][2], dyy[p][3]};
       *reinterpret_cast<f32x4*>(py + 4) = f32x4{dyy[p][4], dyy[p][5], dyy[p][6], dyy[p][7]};
     }
@@ -269,7 +293,8 @@ __global__ __launch_bounds__(256) void k_dora_grads_mfma(const unsigned short* _
 // element e of the slab layout, summed over the nb workgroup slabs, scaled and added to its gradient
 template <int D, int NP>
 __global__ __launch_bounds__(256) void k_dora_reduce(const float* __restrict__ scratch, int nb, const DoraProjs pr) {
-  constexpr int E = NP * D * 21;
+  constexpr int RP = D <= 512 ? 4 : 2;
+  constexpr int E = NP * D * (17 + RP);
   __shared__ float part[4][64];
   const int tid = threadIdx.x, el = tid & 63, sl = tid >> 6;
   const int e = blockIdx.x * 64 + el;
@@ -294,14 +319,14 @@ __global__ __launch_bounds__(256) void k_dora_reduce(const float* __restrict__ s
       atomicAdd(pr.p[p].dm + col, -pr.p[p].bias[col] * sum / pr.p[p].mag[col]);   // - b sum_rows dy
     } else {
       const int q2 = q - NP * D;
-      const int p = q2 / (4 * D), col = q2 % D;
+      const int p = q2 / (RP * D), col = q2 % D;
       atomicAdd(pr.p[p].dm + col, sum / pr.p[p].mag[col]);                        // sum_rows dy y
     }
   }
 }
 
 // scratch the multi-projection kernel wants: one slab of partial sums per workgroup (at most 256 workgroups)
-size_t dora_grads_scratch_bytes(int np, int d) { return (size_t)256 * np * d * 21 * sizeof(float); }
+size_t dora_grads_scratch_bytes(int np, int d) { return (size_t)256 * np * d * 21 * sizeof(float); }   // >= 17 + RP
 
 // np projections (1..3) that read the same X; d in {384, 512}.  Gradients are ACCUMULATED.  scratch (optional):
 // dora_grads_scratch_bytes(np, d) bytes of device memory; without it the slabs come from hipMallocAsync.
@@ -310,7 +335,8 @@ int launch_dora_grads_multi(const void* X, long ldx, const void* dY, const void*
                             const float* scaling, const float* const* A, const float* const* Bm,
                             const float* const* mag, const float* const* nrm, float* const* dA, float* const* dB,
                             float* const* dm, long M, int d, hipStream_t s, void* scratch, size_t scratch_bytes) {
-  GWW_REQUIRE(np >= 1 && np <= 3 && (d == 384 || d == 512), "dora_grads_multi: np=%d d=%d unsupported", np, d);
+  GWW_REQUIRE(np >= 1 && np <= 3 && (d == 384 || d == 512 || (d == 768 && np == 1)),
+              "dora_grads_multi: np=%d d=%d unsupported (d 384 / 512 with up to 3 projections, d 768 with one)", np, d);
   GWW_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "dora_grads_multi: row strides must be multiples of 8 elements");
   if (M == 0) return GWW_OK;
   DoraProjs pr{};
@@ -323,7 +349,7 @@ int launch_dora_grads_multi(const void* X, long ldx, const void* dY, const void*
   long nb = cdiv(M, 32);
   const long nb_max = nb_env > 0 && nb_env < 256 ? nb_env : 256;   // one workgroup per CU (LDS); one slab each
   if (nb > nb_max) nb = nb_max;
-  const size_t lds = (size_t)(1 + np) * 32 * d * 2 + 4096;
+  const size_t lds = (size_t)(1 + np) * 32 * d * 2 + 4096 + (d > 512 ? (size_t)16 * np * (d * 2 + 16) : 0);
   // per-workgroup partial sums: the caller's scratch (encoder workspace) or a stream-ordered allocation
   const size_t need = dora_grads_scratch_bytes(np, d);
   float* slabs = (float*)scratch;
@@ -332,18 +358,20 @@ int launch_dora_grads_multi(const void* X, long ldx, const void* dY, const void*
     GWW_HIP(hipMallocAsync((void**)&slabs, need, s));
     own_alloc = true;
   }
-  const int n_el = np * d * 21;
+  const int n_el = np * d * (17 + (d <= 512 ? 4 : 2));
 #define GWW_DGM(DD, NPP)                                                                                            \
   do {                                                                                                              \
-    GWW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dora_grads_mfma<DD, NPP>),                         \
+    GWW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dora_grads_mfma<DD, NPP, (DD > 512)>),             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
-    hipLaunchKernelGGL((k_dora_grads_mfma<DD, NPP>), dim3((unsigned)nb), dim3(256), lds, s,                         \
+    hipLaunchKernelGGL((k_dora_grads_mfma<DD, NPP, (DD > 512)>), dim3((unsigned)nb), dim3(256), lds, s,             \
                        (const unsigned short*)X, ldx, (const unsigned short*)dY, (const unsigned short*)Y, ldy, pr, \
                        M, slabs);                                                                                   \
     hipLaunchKernelGGL((k_dora_reduce<DD, NPP>), dim3((unsigned)cdiv(n_el, 64)), dim3(256), 0, s, slabs, (int)nb,   \
                        pr);                                                                                         \
   } while (0)
-  if (d == 384) {
+  if (d == 768) {
+    GWW_DGM(768, 1);
+  } else if (d == 384) {
     if (np == 1) GWW_DGM(384, 1); else if (np == 2) GWW_DGM(384, 2); else GWW_DGM(384, 3);
   } else {
     if (np == 1) GWW_DGM(512, 1); else if (np == 2) GWW_DGM(512, 2); else GWW_DGM(512, 3);

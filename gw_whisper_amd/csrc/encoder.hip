@@ -36,7 +36,8 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
                      const float* q_u = nullptr, const float* q_cb = nullptr, void* q_out = nullptr, int NQ = 0);
 int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
                       float yscale, float scaling, const float* A, const float* Bm, const float* mag,
-                      const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s);
+                      const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s,
+                      void* scratch = nullptr, size_t scratch_bytes = 0);
 int launch_dora_grads_multi(const void* X, long ldx, const void* dY, const void* Y, long ldy, int np,
                             const long* col_off, const float* const* bias_st, const float* yscale,
                             const float* scaling, const float* const* A, const float* const* Bm,
@@ -676,7 +677,8 @@ TrainWs train_ws(const gww_enc_cfg& c, int B) {
   w.Dv = take((size_t)B * H * (T + (T + 63) / 64) * 4);   // row dots + live-tile flags
   w.z1 = take(((size_t)B * (Tin + 2) + 256) * d * 2);            // stem backward: conv1 pre-activation / its gradient
   w.col1 = take(((size_t)B * (Tin + 2) + 256) * kConv1Kpad * 2); // stem backward: conv1 taps side by side
-  w.dgs_bytes = (d == 384 || d == 512) ? dora_grads_scratch_bytes(3, (int)d) : 0;   // DoRA-gradient partial sums
+  w.dgs_bytes = (d == 384 || d == 512) ? dora_grads_scratch_bytes(3, (int)d)        // DoRA-gradient partial sums
+                : d == 768 ? dora_grads_scratch_bytes(1, (int)d) : 0;
   w.dgs = take(w.dgs_bytes);
   w.total = off;
   return w;
@@ -840,7 +842,7 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
           have_y = true;
         }
         GWW_TRY(launch_dora_grads(ctx_last, (long)T * d, dxb, dh, d, W.bo, 1.0f, t.scaling, t.A, t.B, t.mag, t.nrm,
-                                  t.dA, t.dB, t.dm, B, d, t.r, s));
+                                  t.dA, t.dB, t.dm, B, d, t.r, s, base + w.dgs, w.dgs_bytes));
       }
       // d(ctx) rows (b, T-1) -> the dense, otherwise zero dctx
       GWW_TRY(launch_gemm_bf16(dxb, d, W.woT, nullptr, nullptr, nullptr, dh, B, d, d, EPI_BIAS, 0, s, 0));
@@ -869,7 +871,7 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
           have_y = true;
         }
         GWW_TRY(launch_dora_grads(ctx, d, dxb, dh, d, W.bo, 1.0f, t.scaling, t.A, t.B, t.mag, t.nrm, t.dA, t.dB, t.dm,
-                                  M, d, t.r, s));
+                                  M, d, t.r, s, base + w.dgs, w.dgs_bytes));
       }
     }
     GWW_TRY(gemm_dx(dxb, d, W.woT, dctx, d, d));
@@ -903,7 +905,7 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
         const long off = (long)t.proj * d;   // q | k | v section
         GWW_TRY(launch_dora_grads(h1, d, (const unsigned short*)dqkv + off, (const unsigned short*)qkv + off, 3L * d,
                                   W.bqkv + off, t.proj == 0 ? 0.125f : 1.0f, t.scaling, t.A, t.B, t.mag, t.nrm, t.dA,
-                                  t.dB, t.dm, M, d, t.r, s));
+                                  t.dB, t.dm, M, d, t.r, s, base + w.dgs, w.dgs_bytes));
       }
     }
     // below layer 0 the gradient only continues into the conv stem: skip it when nobody asked for d_x0 / d_mel

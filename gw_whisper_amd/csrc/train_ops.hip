@@ -579,16 +579,17 @@ size_t dora_grads_scratch_bytes(int np, int d);
 
 int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
                       float yscale, float scaling, const float* A, const float* Bm, const float* mag,
-                      const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s) {
+                      const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s,
+                      void* scratch, size_t scratch_bytes) {
   GWW_REQUIRE(r == 8 && (d == 128 || d == 384 || d == 512 || d == 768 || d == 1024 || d == 1280),
               "dora_grads: only r = 8 and d in {128, 384, 512, 768, 1024, 1280} (got d=%d r=%d)", d, r);
   if (M == 0) return GWW_OK;
   static const int old_kernel = getenv("GWW_DORA_OLD") ? atoi(getenv("GWW_DORA_OLD")) : 0;   // comparison aid: 1 = VALU
   // kernels only, 2 = register-blocked VALU kernel instead of the MFMA kernel
-  if ((d == 384 || d == 512) && !old_kernel) {   // matrix-core kernel (dora_grads.hip)
+  if ((d == 384 || d == 512 || d == 768) && !old_kernel) {   // matrix-core kernel (dora_grads.hip)
     const long off = 0;
     return launch_dora_grads_multi(X, ldx, dY, Y, ldy, 1, &off, &bias_st, &yscale, &scaling, &A, &Bm, &mag, &nrm, &dA, &dB,
-                                   &dm, M, d, s, nullptr, 0);
+                                   &dm, M, d, s, scratch, scratch_bytes);
   }
   if (d <= 768 && d != 128 && old_kernel != 1) {
     static const long nb_env = getenv("GWW_DORA_BLOCKS") ? atol(getenv("GWW_DORA_BLOCKS")) : 0;   // tuning aid
@@ -650,5 +651,5 @@ extern "C" int gww_dora_grads(const void* X, long ldx, const void* dY, const voi
                               void* stream) {
   GWW_REQUIRE(X && dY && Y && bias_st && A && B && mag && nrm && dA && dB && dm, "gww_dora_grads: NULL argument");
   return launch_dora_grads(X, ldx, dY, Y, ldy, bias_st, yscale, scaling, A, B, mag, nrm, dA, dB, dm, M, d, r,
-                           (hipStream_t)stream);
+                           (hipStream_t)stream, nullptr, 0);
 }

@@ -1,7 +1,7 @@
 set -o pipefail
 export TMPDIR=/tmp
 mkdir -p gpurun_out/proft; rm -rf gpurun_out/proft/*
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/proft -o t -- python3 tools/run/train_only.py > gpurun_out/proft.out 2> gpurun_out/proft.err; echo "rc=$?"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/proft -o t -- python3 tools/run/train_only.py small > gpurun_out/proft.out 2> gpurun_out/proft.err; echo "rc=$?"
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/proft/**/t_kernel_stats.csv', recursive=True)[0]

@@ -4,5 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 import bench
 dev = torch.device("cuda:0")
-r = bench.dora_step("tiny", 32, dev, 1, steps=10, warmup=2)
+import sys as _s
+name = _s.argv[1] if len(_s.argv) > 1 else "tiny"
+r = bench.dora_step(name, 32, dev, 1, steps=4 if name != "tiny" else 10, warmup=2)
 print(r)
