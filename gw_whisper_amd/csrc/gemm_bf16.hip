@@ -306,12 +306,13 @@ int launch_gemm_bf16(const void* A, long lda, const void* W, const float* bias, 
   } else if (epi == EPI_RESID) {
     GWW_REQUIRE(resid != nullptr, "gemm_bf16: residual epilogue needs resid");
   }
-  if (rows_padded_256 && N % BN2 == 0 && N <= 1536 && M >= 4096 && epi != EPI_CONV1) {
+  if (rows_padded_256 && N % BN2 == 0 && N <= 6144 && M >= 4096 && epi != EPI_CONV1) {
     // large-M path; the caller has padded A / C / resid to a multiple of 256 rows.
     // (EPI_CONV1 writes row m + 1 and keeps the bounds-checked kernel.)
     const long panels = cdiv(M, BM2);
     const int tn2 = N / BN2;
-    const int n_split = pick_n_split(panels, tn2);
+    int n_split = pick_n_split(panels, tn2);
+    while (cdiv(tn2, n_split) * BN2 > 1536) ++n_split;   // a block's bias slice lives in 1536 floats of LDS
     dim3 grid2((unsigned)(panels * n_split)), block2(512);
 #define GWW_GEMM2_CASE(E)                                                                             \
   case E:                                                                                             \

@@ -110,7 +110,9 @@ def test_cast_bf16_round_to_nearest_even(T, gww):
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 384), (1501, 1152, 384), (777, 384, 1536), (64, 1536, 384),
                                    # M % 256 == 0 and >= 4096: the persistent row-panel kernel (v2)
-                                   (4096, 384, 384), (5120, 1152, 384), (4352, 384, 1536), (4096, 1536, 384), (8192, 128, 128)])
+                                   (4096, 384, 384), (5120, 1152, 384), (4352, 384, 1536), (4096, 1536, 384), (8192, 128, 128),
+                                   # whisper-small widths: N > 1536 runs the same kernel with the columns split over blocks
+                                   (4096, 2304, 768), (4352, 3072, 768), (4096, 768, 3072), (4096, 5120, 128)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_bf16(T, gww, M, N, K, epi):
     from gw_whisper_amd import ops
