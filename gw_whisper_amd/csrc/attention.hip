@@ -283,12 +283,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attention_bf16(con
 //   * K runs one tile ahead of V through the same two LDS buffers each (K(j+2) and V(j+1) are staged at the end
 //     of block j); still one barrier per tile.  The tile loop is unrolled by two so the score registers swap
 //     roles without copies and every LDS address is an immediate.
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsigned short* __restrict__ qkv,
-                                                                    unsigned short* __restrict__ ctx,
-                                                                    float* __restrict__ lse, int T, int H, int q_tiles,
-                                                                    int qt0) {
-  static_assert(NW == 4, "128 query rows per workgroup");
+// MB = 32-row query blocks per wave.  MB = 2 (GWW_ATT_MB=2; 64 rows per wave, one wave per SIMD with the whole
+// register file): one set of K / V fragment reads, waits, addresses and loop overhead feeds twice the MFMAs and
+// exponentials (the kernel above issues ~225 instructions per 20 MFMAs).  Measured: correct, but 1.87 ms per
+// whisper-tiny layer -- with a single wave per SIMD every LDS wait and barrier of the compiler's schedule is
+// exposed (130 cycles per MFMA).  MB = 1 (two waves per SIMD): 1.20 ms; the plain kernel (three waves): 1.13 ms.
+template <int NW, int MB>
+__global__ __launch_bounds__(NW * 64, MB == 1 ? 2 : 1) void k_attention_pipe_bf16(const unsigned short* __restrict__ qkv,
+                                                                               unsigned short* __restrict__ ctx,
+                                                                               float* __restrict__ lse, int T, int H,
+                                                                               int q_tiles, int qt0) {
+  static_assert(NW == 4 && (MB == 1 || MB == 2), "4 waves x MB x 32 query rows per workgroup");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KB * DH * 2];   // 32 KB
   constexpr int TILE_BYTES = KB * DH * 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -304,14 +309,17 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
   const unsigned short* kp = base + d + h * DH;
   const unsigned short* vp = base + 2 * d + h * DH;
   const int r = lane & 31, hh = lane >> 5;
-  const int q_row = qt * (NW * 32) + wave * 32 + r;
-  const int q_ld = q_row < T ? q_row : T - 1;
-
+  int q_row[MB];
   // Q fragments (B operand of K Q^T); q arrives in log2 units (log2(e) / 8 folded into the packed q_proj panel)
-  bf16x8 qf[4];
+  bf16x8 qf[MB][4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
-    qf[s] = *reinterpret_cast<const bf16x8*>(qp + (long)q_ld * row_stride + 16 * s + 8 * hh);
+  for (int m = 0; m < MB; ++m) {
+    q_row[m] = qt * (NW * 32 * MB) + wave * (32 * MB) + 32 * m + r;
+    const int q_ld = q_row[m] < T ? q_row[m] : T - 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      qf[m][s] = *reinterpret_cast<const bf16x8*>(qp + (long)q_ld * row_stride + 16 * s + 8 * hh);
+  }
 
   constexpr int NCH = 512 / (NW * 64);
   int st_row[NCH], st_chunk[NCH];
@@ -355,10 +363,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
       *reinterpret_cast<u32x4*>(lds + (2 + buf) * TILE_BYTES + v_off(st_row[i], st_chunk[i] * 16)) = rv[i];
   };
 
-  f32x16 ot[2], lt, cneg;
+  f32x16 ot[MB][2], lt[MB], cneg[MB];
+  float m_run[MB], tmax[MB];   // log2 units
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { ot[0][j] = 0.f; ot[1][j] = 0.f; lt[j] = 0.f; cneg[j] = 0.f; }
-  float m_run = 0.f;   // log2 units
+  for (int m = 0; m < MB; ++m) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { ot[m][0][j] = 0.f; ot[m][1][j] = 0.f; lt[m][j] = 0.f; cneg[m][j] = 0.f; }
+    m_run[m] = 0.f;
+  }
   bf16x8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
@@ -366,58 +378,44 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
   const int tr_colbyte = (((lane & 31) >> 4) * 16 + 4 * tr_p) * 2;
   const bool ragged = (T % KB) != 0;
   constexpr float kDeferLog2 = 8.0f * kLog2e;
+  typedef f32x16 Scores[MB][2];   // [row block][32-key half]: reg <-> key 32 g + (reg&3) + 8 (reg>>2) + 4 hh
 
-  // S^T of one tile, relative to the current reference: st[g][reg] <-> key 32 g + (reg&3) + 8 (reg>>2) + 4 hh
-  auto scores = [&](f32x16 (&st)[2], int buf) {
+  auto mask_last = [&](Scores& st) {   // keys >= T of the last tile
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(lds + buf * TILE_BYTES + k_off(32 * g + r, 2 * s + hh));
-        st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? cneg : st[g], 0, 0, 0);
-      }
-    }
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int key = (n_kt - 1) * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
+          if (key >= T) st[m][g][j] = -INFINITY;
+        }
   };
-  auto mask_last = [&](f32x16 (&st)[2]) {   // keys >= T of the last tile
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int key = (n_kt - 1) * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
-        if (key >= T) st[g][j] = -INFINITY;
-      }
-  };
-  auto rowmax = [&](const f32x16 (&st)[2]) {
-    float t = st[0][0];
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) t = fmaxf(t, st[g][j]);
-    return fmaxf(t, __shfl_xor(t, 32, 64));
-  };
-  // move the reference by dm (per row): O, l and the scores already computed against the old reference
-  auto rebase = [&](f32x16 (&st)[2], float dm) {
+  // move the reference of row block m by dm (per row): O, l and the scores already computed against the old one
+  auto rebase = [&](Scores& st, int m, float dm) {
     const float alpha = __builtin_amdgcn_exp2f(-dm);
-    m_run += dm;
+    m_run[m] += dm;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      lt[j] *= alpha;
-      ot[0][j] *= alpha;
-      ot[1][j] *= alpha;
-      st[0][j] -= dm;
-      st[1][j] -= dm;
-      cneg[j] = -m_run;
+      lt[m][j] *= alpha;
+      ot[m][0][j] *= alpha;
+      ot[m][1][j] *= alpha;
+      st[m][0][j] -= dm;
+      st[m][1][j] -= dm;
+      cneg[m][j] = -m_run[m];
     }
   };
   // one tile: [S of the next tile] + exp of this tile + P V of this tile (+ row max of the next tile)
-  auto block = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], float& tmax, auto par_c, auto next_c, auto mask_c) {
+  auto block = [&](Scores& sc, Scores& sn, auto par_c, auto next_c, auto mask_c) {
     constexpr int PAR = decltype(par_c)::value;            // tile parity: V buffer PAR, next K buffer PAR ^ 1
     constexpr bool NEXT = decltype(next_c)::value, MASK = decltype(mask_c)::value;
-    if (__builtin_amdgcn_ballot_w64(tmax > kDeferLog2) != 0) rebase(sc, fmaxf(tmax, 0.f));   // wave-uniform, rare
-    // Phase 1: all K fragments of the next tile are requested first, then its 8 S MFMAs (the two 32-key halves
-    // alternate, so no MFMA waits for its predecessor's accumulator) carry 4 of this tile's 32 exponentials each.
-    // Phase 2: 4 x (P -> bf16, 3 MFMAs) with the next V fragments requested one step ahead and the row maximum of
-    // the next tile's scores in the MFMA shadows.  The scheduling groups pin that order.
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+      if (__builtin_amdgcn_ballot_w64(tmax[m] > kDeferLog2) != 0) rebase(sc, m, fmaxf(tmax[m], 0.f));   // rare
+    // Phase 1: all K fragments of the next tile are requested first, then its S MFMAs (the 32-key halves and the
+    // row blocks alternate, so no MFMA waits for its predecessor's accumulator) carry 4 of this tile's
+    // exponentials each.  Phase 2: 4 x (P -> bf16, 3 MFMAs per row block) with the second half's V fragments
+    // requested two steps ahead and the row maximum of the next tile's scores in the MFMA shadows.
     typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
     const unsigned char* vs = lds + (2 + PAR) * TILE_BYTES;
     bf16x8 vfr[4][2];
@@ -446,17 +444,19 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          sn[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[g][s], qf[s], s == 0 ? cneg : sn[g], 0, 0, 0);
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int idx = 4 * (2 * s + g) + j;
-            sc[idx >> 4][idx & 15] = __builtin_amdgcn_exp2f(sc[idx >> 4][idx & 15]);
+          for (int m = 0; m < MB; ++m) {
+            sn[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[g][s], qf[m][s], s == 0 ? cneg[m] : sn[m][g], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int idx = 4 * (2 * s + g) + j;
+              sc[m][idx >> 4][idx & 15] = __builtin_amdgcn_exp2f(sc[m][idx >> 4][idx & 15]);
+            }
           }
-        }
       __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // 8 K + 8 V fragment reads (steps 0 and 1 of phase 2)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 8 * MB; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
         __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);   // 4 v_exp_f32
       }
@@ -464,44 +464,57 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
       load_v(0);
       load_v(1);
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
+      for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) sc[g][j] = __builtin_amdgcn_exp2f(sc[g][j]);
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) sc[m][g][j] = __builtin_amdgcn_exp2f(sc[m][g][j]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    load_v(2);   // the second half's V fragments: two steps (6 MFMAs) ahead of their use
+    load_v(2);   // the second half's V fragments: two steps ahead of their use
     load_v(3);
-    float t = -INFINITY;
+    float t[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) t[m] = -INFINITY;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int g = c >> 1, s2 = c & 1;
-      const bf16x8 pf = cvt8(sc[g], 8 * s2);
-      lt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lt, 0, 0, 0);
-      ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[c][0], pf, ot[0], 0, 0, 0);
-      ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[c][1], pf, ot[1], 0, 0, 0);
-      if constexpr (NEXT) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int reg = 8 * s2 + j;
-          if constexpr (MASK) {
-            const int key = (n_kt - 1) * KB + 32 * g + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-            if (key >= T) sn[g][reg] = -INFINITY;
+      for (int m = 0; m < MB; ++m) {
+        const bf16x8 pf = cvt8(sc[m][g], 8 * s2);
+        lt[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lt[m], 0, 0, 0);
+        ot[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[c][0], pf, ot[m][0], 0, 0, 0);
+        ot[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[c][1], pf, ot[m][1], 0, 0, 0);
+        if constexpr (NEXT) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int reg = 8 * s2 + j;
+            if constexpr (MASK) {
+              const int key = (n_kt - 1) * KB + 32 * g + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+              if (key >= T) sn[m][g][reg] = -INFINITY;
+            }
+            t[m] = fmaxf(t[m], sn[m][g][reg]);
           }
-          t = fmaxf(t, sn[g][reg]);
         }
       }
       if constexpr (!MASK) {
         if (c == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // V fragments of steps 2 and 3
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);               // 4 cvt_pk
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);               // row maximum of the next tile
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);               // 4 cvt_pk
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);               // row maximum of the next tile
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (NEXT) tmax = fmaxf(t, __shfl_xor(t, 32, 64));
+    if constexpr (NEXT) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m) tmax[m] = fmaxf(t[m], __shfl_xor(t[m], 32, 64));
+    }
   };
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
@@ -509,23 +522,39 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
   using No = std::false_type;
 
   // ---- prologue: S(0) against reference 0, then the reference becomes the row maximum of tile 0
-  f32x16 sa[2], sb[2];
+  Scores sa, sb;
   gload_k(0);
   lstore_k(0);
   if (n_kt > 1) gload_k(1);
   gload_v(0);
   __syncthreads();
-  scores(sa, 0);
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(lds + k_off(32 * g + r, 2 * s + hh));
+        sa[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[m][s], s == 0 ? cneg[m] : sa[m][g], 0, 0, 0);
+      }
   if (n_kt == 1 && ragged) mask_last(sa);
-  float tmax = rowmax(sa);
-  rebase(sa, tmax);
-  tmax = 0.f;
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+    float t = sa[m][0][0];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) t = fmaxf(t, sa[m][g][j]);
+    t = fmaxf(t, __shfl_xor(t, 32, 64));
+    rebase(sa, m, t);
+    tmax[m] = 0.f;
+  }
   if (n_kt > 1) lstore_k(1);
   lstore_v(0);
   __syncthreads();
 
   // steady state at tile kt (parity PAR): LDS holds K(kt+1) [K buffer PAR^1] and V(kt) [V buffer PAR]
-  auto main_iter = [&](int kt, f32x16 (&sc)[2], f32x16 (&sn)[2], auto par_c) {   // needs kt + 2 < n_kt
+  auto main_iter = [&](int kt, Scores& sc, Scores& sn, auto par_c) {   // needs kt + 2 < n_kt
     constexpr int PAR = decltype(par_c)::value;
 #ifdef GWW_ATT_NOLOAD   // diagnostic: no K / V traffic in the steady state (wrong results)
     if (kt < 0) {
@@ -535,16 +564,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
 #ifdef GWW_ATT_NOLOAD
     }
 #endif
-    block(sc, sn, tmax, par_c, Yes{}, No{});
+    block(sc, sn, par_c, Yes{}, No{});
     lstore_k(PAR);
     lstore_v(PAR ^ 1);
     __syncthreads();
   };
-  auto prelast_iter = [&](int kt, f32x16 (&sc)[2], f32x16 (&sn)[2], auto par_c) {   // kt + 2 == n_kt
+  auto prelast_iter = [&](int kt, Scores& sc, Scores& sn, auto par_c) {   // kt + 2 == n_kt
     constexpr int PAR = decltype(par_c)::value;
     gload_v(kt + 1);
-    if (ragged) block(sc, sn, tmax, par_c, Yes{}, Yes{});
-    else block(sc, sn, tmax, par_c, Yes{}, No{});
+    if (ragged) block(sc, sn, par_c, Yes{}, Yes{});
+    else block(sc, sn, par_c, Yes{}, No{});
     lstore_v(PAR ^ 1);
     __syncthreads();
   };
@@ -557,28 +586,32 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attention_pipe_bf16(const unsign
   if (rem == 3) {
     main_iter(kt, sa, sb, P0{});
     prelast_iter(kt + 1, sb, sa, P1{});
-    block(sa, sb, tmax, P0{}, No{}, No{});
+    block(sa, sb, P0{}, No{}, No{});
   } else if (rem == 2) {
     prelast_iter(kt, sa, sb, P0{});
-    block(sb, sa, tmax, P1{}, No{}, No{});
+    block(sb, sa, P1{}, No{}, No{});
   } else {
-    block(sa, sb, tmax, P0{}, No{}, No{});
+    block(sa, sb, P0{}, No{}, No{});
   }
 
-  const float l_tot = lt[0];
-  const float inv = 1.0f / l_tot;
-  if (lse && q_row < T && hh == 0) lse[((long)b * H + h) * T + q_row] = (m_run + __log2f(l_tot)) * 0.69314718055994530942f;
-  if (q_row < T) {
-    unsigned short* orow = ctx + ((long)b * T + q_row) * d + h * DH;
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+  for (int m = 0; m < MB; ++m) {
+    const float l_tot = lt[m][0];
+    const float inv = 1.0f / l_tot;
+    if (lse && q_row[m] < T && hh == 0)
+      lse[((long)b * H + h) * T + q_row[m]] = (m_run[m] + __log2f(l_tot)) * 0.69314718055994530942f;
+    if (q_row[m] < T) {
+      unsigned short* orow = ctx + ((long)b * T + q_row[m]) * d + h * DH;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int dh = 32 * n + 8 * c + 4 * hh;
-        u32x2 o = {pack2bf(ot[n][4 * c] * inv, ot[n][4 * c + 1] * inv),
-                   pack2bf(ot[n][4 * c + 2] * inv, ot[n][4 * c + 3] * inv)};
-        *reinterpret_cast<u32x2*>(orow + dh) = o;
-      }
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int dh = 32 * n + 8 * c + 4 * hh;
+          u32x2 o = {pack2bf(ot[m][n][4 * c] * inv, ot[m][n][4 * c + 1] * inv),
+                     pack2bf(ot[m][n][4 * c + 2] * inv, ot[m][n][4 * c + 3] * inv)};
+          *reinterpret_cast<u32x2*>(orow + dh) = o;
+        }
+    }
   }
 }
 
@@ -605,12 +638,17 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
   // 128 query rows per workgroup, two workgroups per CU; the 256-row form (one per CU, K / V streamed once per
   // 256 queries) measures 5 % slower at T = 1500 -- the kernel is issue-bound, not L2-bound
   const int nw = (nw_env == 8 && !q_log2) ? 8 : 4;
-  const int all_tiles = (T + nw * 32 - 1) / (nw * 32);
+  static const int mb_env = getenv("GWW_ATT_MB") ? atoi(getenv("GWW_ATT_MB")) : 1;   // pipelined kernel: row blocks per wave
+  const int mb = q_log2 ? (mb_env == 2 ? 2 : 1) : 1;
+  const int all_tiles = (T + nw * 32 * mb - 1) / (nw * 32 * mb);
   const int q_tiles = last_tile_only ? 1 : all_tiles, qt0 = last_tile_only ? all_tiles - 1 : 0;
   const long blocks = (long)q_tiles * B * H;
   GWW_REQUIRE(blocks < 2147483647L, "attention_bf16: grid too large");
-  if (q_log2)
-    hipLaunchKernelGGL(k_attention_pipe_bf16<4>, dim3((unsigned)blocks), dim3(256), 0, s,
+  if (q_log2 && mb == 2)
+    hipLaunchKernelGGL((k_attention_pipe_bf16<4, 2>), dim3((unsigned)blocks), dim3(256), 0, s,
+                       (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles, qt0);
+  else if (q_log2)
+    hipLaunchKernelGGL((k_attention_pipe_bf16<4, 1>), dim3((unsigned)blocks), dim3(256), 0, s,
                        (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles, qt0);
   else if (nw == 8)
     hipLaunchKernelGGL(k_attention_bf16<8>, dim3((unsigned)blocks), dim3(512), 0, s,
