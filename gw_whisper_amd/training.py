@@ -70,14 +70,27 @@ class _EncoderTrain(torch.autograd.Function):
         targets = dora_targets(enc)
         arr = (_lib.DoraTarget * max(len(targets), 1))()
         grads, keep = [], []
+        def grad_buffer(param, like):
+            # The HIP backward ACCUMULATES into the buffers it is given.  When the parameter already owns a dense fp32
+            # .grad (optimizer.zero_grad(set_to_none=False), dist.FlatGradBucket views) it accumulates straight into
+            # that and autograd gets None for this input -- no zeros_like + add kernel per tensor (96 tiny launches
+            # per whisper-tiny step).  Otherwise: a fresh zero buffer handed back to autograd as usual.
+            g = param.grad
+            if (g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == like.device
+                    and g.shape == like.shape and not g.requires_grad):
+                return g, None
+            z = torch.zeros_like(like)
+            return z, z
         for i, (li, pid, mod) in enumerate(targets):
-            A = mod.lora_A[mod.adapter].weight.detach().float().contiguous()
-            Bm = mod.lora_B[mod.adapter].weight.detach().float().contiguous()
-            mag = mod.lora_magnitude_vector[mod.adapter].weight.detach().float().contiguous()
+            pA, pB, pm = (mod.lora_A[mod.adapter].weight, mod.lora_B[mod.adapter].weight,
+                          mod.lora_magnitude_vector[mod.adapter].weight)
+            A = pA.detach().float().contiguous()
+            Bm = pB.detach().float().contiguous()
+            mag = pm.detach().float().contiguous()
             nrm = mod._last_norm
-            dA, dB, dm = torch.zeros_like(A), torch.zeros_like(Bm), torch.zeros_like(mag)
-            keep += [A, Bm, mag]
-            grads.append((dA, dB, dm))
+            (dA, rA), (dB, rB), (dm, rm) = grad_buffer(pA, A), grad_buffer(pB, Bm), grad_buffer(pm, mag)
+            keep += [A, Bm, mag, dA, dB, dm]
+            grads.append((rA, rB, rm))
             arr[i] = _lib.DoraTarget(li, pid, mod.r, float(mod.scaling), A.data_ptr(), Bm.data_ptr(), mag.data_ptr(),
                                      nrm.data_ptr(), dA.data_ptr(), dB.data_ptr(), dm.data_ptr())
         # gradient w.r.t. the input features (conv stem backward) only when autograd asks for it

@@ -277,6 +277,44 @@ def test_training_step_matches_finite_differences(T, gww, projs, pooled):
         assert abs(an - fd) < 0.06 * abs(fd) + 2e-3, (an, fd)
 
 
+def test_gradients_accumulate_into_existing_grad_buffers(T, gww):
+    """With dense fp32 .grad buffers already in place (zero_grad(set_to_none=False), FlatGradBucket views) the HIP
+    backward accumulates straight into them; with .grad None it hands fresh tensors to autograd.  Same numbers, and a
+    second backward adds on top in both modes."""
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    from gw_whisper_amd.peft import LoraConfig, get_peft_model
+    sd = synth.encoder_state_dict(128, 2, 2, 512, seed=3)
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig(128, 2, 2, 512), precision="bf16")
+    targets = [f"layers.{i}.self_attn.{p}" for i in range(2) for p in ("q_proj", "v_proj")]
+    peft = get_peft_model(enc, LoraConfig(use_dora=True, r=8, lora_alpha=32, target_modules=targets)).cuda()
+    with T.no_grad():
+        for j, name in enumerate(targets):
+            peft.base_model.model.get_submodule(name).lora_B["default"].weight.normal_(
+                0.0, 0.02, generator=T.Generator(device="cuda").manual_seed(j))
+    mel = T.from_numpy(olm.log_mel(synth.strain_segments(2, seed=8))).cuda()
+    params = [p for n, p in peft.named_parameters() if "lora_" in n]
+
+    def run():
+        peft.last_token(mel).square().sum().backward()
+        return [p.grad.clone() for p in params]
+
+    for p in params:
+        p.grad = None
+    returned = run()                                   # autograd receives the tensors
+    for p in params:
+        p.grad = T.zeros_like(p)
+    held = [p.grad for p in params]
+    direct = run()                                     # accumulated in place
+    assert all(p.grad is h for p, h in zip(params, held)), "the existing buffers must be kept"
+    twice = run()
+    for a, b, c in zip(returned, direct, twice):
+        scale = a.abs().max().item() + 1e-12
+        assert a.abs().max().item() > 0
+        # identical kernels; only the fp32 atomics of the small-d DoRA kernel reorder sums
+        assert (a - b).abs().max().item() < 1e-4 * scale
+        assert (c - 2 * a).abs().max().item() < 2e-4 * scale
+
+
 def test_whisper_small_dora_step_runs(T, gww):
     """BASELINE config 3 geometry (whisper-small, DoRA r=8 alpha=32 on q, k, v, out_proj = 48 targets,
     626 688 adapter parameters): the training forward agrees with the inference forward and every adapter
