@@ -117,7 +117,7 @@ def kernel_breakdown(enc_name, B, dev):
     return rows
 
 
-def dora_step(enc_name, per_gpu_batch, dev, world, steps=3, warmup=1):
+def dora_step(enc_name, per_gpu_batch, dev, world, steps=6, warmup=2):
     """DoRA fine-tuning step as in Signal_vs_Noise/src/train.py:163-168,263-277: whisper encoder with
     DoRA (r=8, alpha=32) on q/k/v, two-detector MLP head, BCEWithLogits, AdamW over the 'lora' + head
     parameters; forward + backward in libgww, head / loss / optimizer in torch; gradients of the
@@ -161,6 +161,9 @@ def dora_step(enc_name, per_gpu_batch, dev, world, steps=3, warmup=1):
         opt.step()
         e[4].record()
         torch.cuda.synchronize()
+        if os.environ.get("GWW_BENCH_VERBOSE"):
+            print(f"[dora_step] it {it}: " + " ".join(f"{k}={e[i].elapsed_time(e[i + 1]):.2f}" for k, i in
+                  (("fwd", 0), ("bwd", 1), ("allreduce", 2), ("opt", 3))), file=sys.stderr, flush=True)
         if it >= warmup:
             for k, i in (("fwd", 0), ("bwd", 1), ("allreduce", 2), ("opt", 3)):
                 times[k] += e[i].elapsed_time(e[i + 1]) / steps
