@@ -64,8 +64,11 @@ __device__ __forceinline__ bf16x8 cvt8(const f32x16& a, int base) {
 // NW waves x 32 query rows per workgroup.  NW = 8 (256 rows, one workgroup per CU) streams every K / V tile
 // once per 256 queries: at 128 rows per workgroup the kernel needed 32 B/clk/CU of K / V from L2 -- the whole L2
 // bandwidth of an XCD -- and spent 60 % of its cycles waiting for the next tile (tools/stamp_att.py).
+#ifndef GWW_ATT_MINBLK
+#define GWW_ATT_MINBLK 2   // tuning aid: 2 lets the allocator use 168 VGPRs (3 waves / SIMD); 4 forces 128 (spills)
+#endif
 template <int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_attention_bf16(const unsigned short* __restrict__ qkv,
+__global__ __launch_bounds__(NW * 64, NW == 4 ? GWW_ATT_MINBLK : 1) void k_attention_bf16(const unsigned short* __restrict__ qkv,
                                                            unsigned short* __restrict__ ctx,
                                                            float* __restrict__ lse, int T, int H,
                                                            int q_tiles, int qt0) {
