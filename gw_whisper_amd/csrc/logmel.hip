@@ -17,6 +17,8 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 namespace gww {
@@ -153,6 +155,166 @@ __global__ __launch_bounds__(256) void k_logmel_frames(const float* __restrict__
   }
 }
 
+// ---- the same stage on the fp32 matrix cores (default; GWW_LOGMEL_VALU=1 selects the kernel above) ----
+// The VALU kernel issues ~8.5 k instructions per wave for 8 frames (one thread per frequency bin, 3264 FMAs each):
+// instruction issue, not HBM, bounds it (273 us per 256 segments against ~60 us of traffic).  Here a workgroup
+// owns 32 frames and both contractions are v_mfma_f32_32x32x2_f32 chains (exact fp32 products, fp32 accumulate):
+//   re[f][k] = sum_n ev[f][n] cos(2 pi k n / 400),  im[f][k] = sum_n od[f][n] sin(...)      n = 0..200
+//       A operand = ev / od rows from LDS (frame on M), B operand = ONE twiddle-table read per lane per MFMA
+//       (index k n mod 400 advanced by 2 k per step) -- no [201 x 201] table exists anywhere;
+//   mel[f][m] = sum_k P[f][k] fb[k][m]: A = the power tile in LDS, B = the filterbank read coalesced from L2.
+// log10 (fp64, as above), the per-segment maximum, and a transpose through LDS so that every store instruction
+// writes 32 consecutive frames (128 B) of a mel row instead of 4 bytes each into 64 different rows.
+constexpr int kMT = 32;                           // frames per workgroup
+constexpr int kMSpan = kHop * (kMT - 1) + kNfft;  // 5360 samples per tile
+constexpr int kEvS = 205;                         // row stride of ev / od / pw: odd -> conflict-free column reads
+
+__global__ __launch_bounds__(256) void k_logmel_frames_mfma(const float* __restrict__ wav, long stride, int n_eff,
+                                                            int live, Tables tb, float* __restrict__ out,
+                                                            unsigned int* __restrict__ seg_max) {
+  __shared__ __attribute__((aligned(16))) float xs[kMSpan];       // 21.4 KB; reused as the [80][33] output tile
+  __shared__ float ev[kMT * kEvS];                               // 26.2 KB; reused as the power tile
+  __shared__ float od[kMT * kEvS];
+  __shared__ float ct[kNfft];
+  __shared__ float st[kNfft];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int seg = blockIdx.y;
+  const int t0 = blockIdx.x * kMT;
+  const float* x = wav + (long)seg * stride;
+
+  for (int i = tid; i < kMSpan; i += 256) {
+    int p = t0 * kHop - kNfft / 2 + i;
+    if (p < 0) p = -p;
+    if (p >= kChunk) p = 2 * (kChunk - 1) - p;
+    xs[i] = (p >= 0 && p < n_eff) ? x[p] : 0.0f;
+  }
+  for (int i = tid; i < kNfft; i += 256) {
+    ct[i] = tb.cost[i];
+    st[i] = tb.sint[i];
+  }
+  __syncthreads();
+  // windowed even / odd parts; columns 201..204 are zero (the k-loop runs to 202)
+  for (int i = tid; i < kMT * kEvS; i += 256) {
+    const int f = i / kEvS, n = i - f * kEvS;
+    float e = 0.f, o = 0.f;
+    if (n <= 200) {
+      const float a = xs[f * kHop + n] * tb.win[n];
+      if (n == 0 || n == 200) {
+        e = a;
+      } else {
+        const float b = xs[f * kHop + kNfft - n] * tb.win[kNfft - n];
+        e = a + b;
+        o = a - b;
+      }
+    }
+    ev[i] = e;
+    od[i] = o;
+  }
+  __syncthreads();
+
+  // ---- DFT: 7 blocks of 32 bins; wave w takes blocks w and w + 4.  acc[4 c + e] <-> frame 8 c + 4 hh + e, bin on the lane
+  constexpr int NBLK = 7, NSTEP = 101;   // 2 n per step: n = 0 .. 201
+  f32x16 re[2], im[2];
+  int bin[2], idx[2], inc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { re[q][j] = 0.f; im[q][j] = 0.f; }
+    const int blk = wave + 4 * q;
+    bin[q] = 32 * blk + r;
+    if (bin[q] > 200) bin[q] = 200;            // padding lanes recompute bin 200; never stored
+    idx[q] = (bin[q] * hh) % kNfft;            // n = hh at step 0
+    inc[q] = (2 * bin[q]) % kNfft;
+  }
+  const bool two = wave + 4 < NBLK;            // wave 3 owns one block only (wave-uniform)
+  auto dft = [&](auto two_c) {                 // branch-free loop bodies: the operand reads of step s + 1 are issued
+    constexpr bool TWO = decltype(two_c)::value;   // under the MFMAs of step s
+    const float* evr = ev + r * kEvS + hh;
+    const float* odr = od + r * kEvS + hh;
+#pragma unroll 2
+    for (int s = 0; s < NSTEP; ++s) {
+      const float ae = evr[2 * s];
+      const float ao = odr[2 * s];
+      re[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, ct[idx[0]], re[0], 0, 0, 0);
+      im[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, st[idx[0]], im[0], 0, 0, 0);
+      idx[0] += inc[0];
+      idx[0] -= idx[0] >= kNfft ? kNfft : 0;
+      if constexpr (TWO) {
+        re[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, ct[idx[1]], re[1], 0, 0, 0);
+        im[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, st[idx[1]], im[1], 0, 0, 0);
+        idx[1] += inc[1];
+        idx[1] -= idx[1] >= kNfft ? kNfft : 0;
+      }
+    }
+  };
+  if (two) dft(std::true_type{});
+  else dft(std::false_type{});
+  __syncthreads();   // everyone is done reading ev / od
+  // power tile pw[f][k] over ev; columns 201..204 zero
+  float* pw = ev;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int k = 32 * (wave + 4 * q) + r;
+    if ((q == 0 || two) && k < kEvS) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int f = 8 * c + 4 * hh + e;
+          pw[f * kEvS + k] = k <= 200 ? re[q][4 * c + e] * re[q][4 * c + e] + im[q][4 * c + e] * im[q][4 * c + e] : 0.f;
+        }
+    }
+  }
+  __syncthreads();
+
+  // ---- mel projection: 3 blocks of 32 mels on waves 0..2; acc[4 c + e] <-> frame 8 c + 4 hh + e, mel on the lane
+  float* tile = xs;                            // [80][33] raw log-mel of this tile
+  float lmax = -INFINITY;
+  if (wave < 3) {
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    int m = 32 * wave + r;
+    const bool live_m = m < kNmel;
+    if (!live_m) m = kNmel - 1;
+    const float* fb = tb.fbT + m;
+#pragma unroll 4
+    for (int s = 0; s < NSTEP; ++s) {
+      const int k = 2 * s + hh;                // k = 201 meets a zero power column
+      const float b = fb[(k <= 200 ? k : 200) * kNmel];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pw[r * kEvS + k], b, acc, 0, 0, 0);
+    }
+    if (live_m) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[m * 33 + 8 * c + 4 * hh + e] = acc[4 * c + e];
+    }
+  }
+  __syncthreads();
+  // log10 in fp64, rounded once (see the VALU kernel), spread over all 256 threads
+  for (int i = tid; i < kNmel * kMT; i += 256) {
+    const int m = i >> 5, f = i & 31;
+    const float lg = (float)log10((double)fmaxf(tile[m * 33 + f], 1e-10f));
+    tile[m * 33 + f] = lg;
+    if (t0 + f < live) lmax = fmaxf(lmax, lg);
+  }
+  lmax = wave_max(lmax);
+  if (lane == 0) red[wave] = lmax;
+  __syncthreads();
+  if (tid == 0) {
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > -INFINITY) atomicMax(&seg_max[seg], fkey(m));
+  }
+  // whole 128-byte runs of a mel row per store instruction
+  for (int i = tid; i < kNmel * kMT; i += 256) {
+    const int m = i >> 5, f = i & 31;
+    if (t0 + f < live) out[((long)seg * kNmel + m) * kFrames + t0 + f] = tile[m * 33 + f];
+  }
+}
+
 // grid (80, n_seg), 256 threads: one [3000] row per workgroup
 __global__ __launch_bounds__(256) void k_logmel_finalize(float* __restrict__ out, int live,
                                                          const unsigned int* __restrict__ seg_max) {
@@ -267,9 +429,16 @@ extern "C" int gww_logmel_f32(gww_frontend* fe, const float* wave, int n_seg, in
     if (live < 1) live = 1;
   }
   GWW_HIP(hipMemsetAsync(seg_max, 0, sizeof(float) * (size_t)n_seg, s));
-  dim3 g1((unsigned)cdiv(live, kFT), (unsigned)n_seg);
-  hipLaunchKernelGGL(k_logmel_frames, g1, dim3(256), 0, s, wave, wave_stride, n_eff, live, fe->tb, out,
-                     reinterpret_cast<unsigned int*>(seg_max));
+  static const bool valu_kernel = getenv("GWW_LOGMEL_VALU") != nullptr;   // comparison aid
+  if (valu_kernel) {
+    dim3 g1((unsigned)cdiv(live, kFT), (unsigned)n_seg);
+    hipLaunchKernelGGL(k_logmel_frames, g1, dim3(256), 0, s, wave, wave_stride, n_eff, live, fe->tb, out,
+                       reinterpret_cast<unsigned int*>(seg_max));
+  } else {
+    dim3 g1((unsigned)cdiv(live, kMT), (unsigned)n_seg);
+    hipLaunchKernelGGL(k_logmel_frames_mfma, g1, dim3(256), 0, s, wave, wave_stride, n_eff, live, fe->tb, out,
+                       reinterpret_cast<unsigned int*>(seg_max));
+  }
   GWW_LAUNCH_CHECK();
   dim3 g2(kNmel, (unsigned)n_seg);
   hipLaunchKernelGGL(k_logmel_finalize, g2, dim3(256), 0, s, out, live,
