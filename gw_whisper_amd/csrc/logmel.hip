@@ -233,8 +233,7 @@ __global__ __launch_bounds__(256) void k_logmel_frames_mfma(const float* __restr
     constexpr bool TWO = decltype(two_c)::value;   // under the MFMAs of step s
     const float* evr = ev + r * kEvS + hh;
     const float* odr = od + r * kEvS + hh;
-#pragma unroll 2
-    for (int s = 0; s < NSTEP; ++s) {
+    auto step = [&](int s) {
       const float ae = evr[2 * s];
       const float ao = odr[2 * s];
       re[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, ct[idx[0]], re[0], 0, 0, 0);
@@ -247,7 +246,16 @@ __global__ __launch_bounds__(256) void k_logmel_frames_mfma(const float* __restr
         idx[1] += inc[1];
         idx[1] -= idx[1] >= kNfft ? kNfft : 0;
       }
+    };
+    // a real loop (4 steps per trip): fully unrolled, the two variants are 40 KB of straight-line code
+#pragma unroll 1
+    for (int s = 0; s + 3 < NSTEP; s += 4) {
+      step(s);
+      step(s + 1);
+      step(s + 2);
+      step(s + 3);
     }
+    step(NSTEP - 1);   // NSTEP = 101 = 4 * 25 + 1
   };
   if (two) dft(std::true_type{});
   else dft(std::false_type{});
@@ -280,11 +288,21 @@ __global__ __launch_bounds__(256) void k_logmel_frames_mfma(const float* __restr
     const bool live_m = m < kNmel;
     if (!live_m) m = kNmel - 1;
     const float* fb = tb.fbT + m;
-#pragma unroll 4
-    for (int s = 0; s < NSTEP; ++s) {
-      const int k = 2 * s + hh;                // k = 201 meets a zero power column
-      const float b = fb[(k <= 200 ? k : 200) * kNmel];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pw[r * kEvS + k], b, acc, 0, 0, 0);
+    // k = 2 s + hh; k = 201 (last step, upper half-wave) meets a zero power column.  Four filterbank values are
+    // requested before the four MFMAs that use them.
+    const float* pwr = pw + r * kEvS + hh;
+    const float* fbk = fb + (long)hh * kNmel;
+#pragma unroll 1
+    for (int s = 0; s + 3 < NSTEP; s += 4) {
+      float b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = fbk[(long)(2 * (s + u)) * kNmel];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pwr[2 * (s + u)], b[u], acc, 0, 0, 0);
+    }
+    {
+      const int k = 2 * (NSTEP - 1) + hh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pw[r * kEvS + k], fb[(k <= 200 ? k : 200) * kNmel], acc, 0, 0, 0);
     }
     if (live_m) {
 #pragma unroll
