@@ -13,7 +13,7 @@ with open(dst, "w") as f:
     for r in rows:
         if float(r["Percentage"]) < 0.01:
             continue
-        name = r["Name"].split("(")[0].replace("void ", "")
+        name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         f.write(f"| `{name}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | "
                 f"{int(r['MinNs'])/1e3:.1f} | {int(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |\n")
 print(open(dst).read())
