@@ -166,10 +166,11 @@ __global__ __launch_bounds__(256) void k_logmel_frames(const float* __restrict__
 // log10 (fp64, as above), the per-segment maximum, and a transpose through LDS so that every store instruction
 // writes 32 consecutive frames (128 B) of a mel row instead of 4 bytes each into 64 different rows.
 constexpr int kMT = 32;                           // frames per workgroup
+constexpr int kMThreads = 512;                    // 8 waves: 7 DFT bin blocks + latency hiding for the row-wise phases
 constexpr int kMSpan = kHop * (kMT - 1) + kNfft;  // 5360 samples per tile
 constexpr int kEvS = 205;                         // row stride of ev / od / pw: odd -> conflict-free column reads
 
-__global__ __launch_bounds__(256) void k_logmel_frames_mfma(const float* __restrict__ wav, long stride, int n_eff,
+__global__ __launch_bounds__(kMThreads) void k_logmel_frames_mfma(const float* __restrict__ wav, long stride, int n_eff,
                                                             int live, Tables tb, float* __restrict__ out,
                                                             unsigned int* __restrict__ seg_max) {
   __shared__ __attribute__((aligned(16))) float xs[kMSpan];       // 21.4 KB; reused as the [80][33] output tile
@@ -177,26 +178,26 @@ __global__ __launch_bounds__(256) void k_logmel_frames_mfma(const float* __restr
   __shared__ float od[kMT * kEvS];
   __shared__ float ct[kNfft];
   __shared__ float st[kNfft];
-  __shared__ float red[4];
+  __shared__ float red[kMThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int seg = blockIdx.y;
   const int t0 = blockIdx.x * kMT;
   const float* x = wav + (long)seg * stride;
 
-  for (int i = tid; i < kMSpan; i += 256) {
+  for (int i = tid; i < kMSpan; i += kMThreads) {
     int p = t0 * kHop - kNfft / 2 + i;
     if (p < 0) p = -p;
     if (p >= kChunk) p = 2 * (kChunk - 1) - p;
     xs[i] = (p >= 0 && p < n_eff) ? x[p] : 0.0f;
   }
-  for (int i = tid; i < kNfft; i += 256) {
+  for (int i = tid; i < kNfft; i += kMThreads) {
     ct[i] = tb.cost[i];
     st[i] = tb.sint[i];
   }
   __syncthreads();
   // windowed even / odd parts; columns 201..204 are zero (the k-loop runs to 202)
-  for (int i = tid; i < kMT * kEvS; i += 256) {
+  for (int i = tid; i < kMT * kEvS; i += kMThreads) {
     const int f = i / kEvS, n = i - f * kEvS;
     float e = 0.f, o = 0.f;
     if (n <= 200) {
@@ -214,40 +215,26 @@ __global__ __launch_bounds__(256) void k_logmel_frames_mfma(const float* __restr
   }
   __syncthreads();
 
-  // ---- DFT: 7 blocks of 32 bins; wave w takes blocks w and w + 4.  acc[4 c + e] <-> frame 8 c + 4 hh + e, bin on the lane
+  // ---- DFT: 7 blocks of 32 bins, one per wave (wave 7 idles here); the re and im chains of a block share the twiddle
+  // index.  acc[4 c + e] <-> frame 8 c + 4 hh + e, bin on the lane
   constexpr int NBLK = 7, NSTEP = 101;   // 2 n per step: n = 0 .. 201
-  f32x16 re[2], im[2];
-  int bin[2], idx[2], inc[2];
+  f32x16 re, im;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { re[q][j] = 0.f; im[q][j] = 0.f; }
-    const int blk = wave + 4 * q;
-    bin[q] = 32 * blk + r;
-    if (bin[q] > 200) bin[q] = 200;            // padding lanes recompute bin 200; never stored
-    idx[q] = (bin[q] * hh) % kNfft;            // n = hh at step 0
-    inc[q] = (2 * bin[q]) % kNfft;
-  }
-  const bool two = wave + 4 < NBLK;            // wave 3 owns one block only (wave-uniform)
-  auto dft = [&](auto two_c) {                 // branch-free loop bodies: the operand reads of step s + 1 are issued
-    constexpr bool TWO = decltype(two_c)::value;   // under the MFMAs of step s
+  for (int j = 0; j < 16; ++j) { re[j] = 0.f; im[j] = 0.f; }
+  if (wave < NBLK) {
+    int bin = 32 * wave + r;
+    if (bin > 200) bin = 200;                  // padding lanes recompute bin 200; never stored
+    int idx = (bin * hh) % kNfft;              // n = hh at step 0
+    const int inc = (2 * bin) % kNfft;
     const float* evr = ev + r * kEvS + hh;
     const float* odr = od + r * kEvS + hh;
     auto step = [&](int s) {
-      const float ae = evr[2 * s];
-      const float ao = odr[2 * s];
-      re[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, ct[idx[0]], re[0], 0, 0, 0);
-      im[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, st[idx[0]], im[0], 0, 0, 0);
-      idx[0] += inc[0];
-      idx[0] -= idx[0] >= kNfft ? kNfft : 0;
-      if constexpr (TWO) {
-        re[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, ct[idx[1]], re[1], 0, 0, 0);
-        im[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, st[idx[1]], im[1], 0, 0, 0);
-        idx[1] += inc[1];
-        idx[1] -= idx[1] >= kNfft ? kNfft : 0;
-      }
+      re = __builtin_amdgcn_mfma_f32_32x32x2f32(evr[2 * s], ct[idx], re, 0, 0, 0);
+      im = __builtin_amdgcn_mfma_f32_32x32x2f32(odr[2 * s], st[idx], im, 0, 0, 0);
+      idx += inc;
+      idx -= idx >= kNfft ? kNfft : 0;
     };
-    // a real loop (4 steps per trip): fully unrolled, the two variants are 40 KB of straight-line code
+    // a real loop (4 steps per trip): fully unrolled this is tens of KB of straight-line code
 #pragma unroll 1
     for (int s = 0; s + 3 < NSTEP; s += 4) {
       step(s);
@@ -256,22 +243,19 @@ __global__ __launch_bounds__(256) void k_logmel_frames_mfma(const float* __restr
       step(s + 3);
     }
     step(NSTEP - 1);   // NSTEP = 101 = 4 * 25 + 1
-  };
-  if (two) dft(std::true_type{});
-  else dft(std::false_type{});
+  }
   __syncthreads();   // everyone is done reading ev / od
   // power tile pw[f][k] over ev; columns 201..204 zero
   float* pw = ev;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int k = 32 * (wave + 4 * q) + r;
-    if ((q == 0 || two) && k < kEvS) {
+  {
+    const int k = 32 * wave + r;
+    if (wave < NBLK && k < kEvS) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int f = 8 * c + 4 * hh + e;
-          pw[f * kEvS + k] = k <= 200 ? re[q][4 * c + e] * re[q][4 * c + e] + im[q][4 * c + e] * im[q][4 * c + e] : 0.f;
+          pw[f * kEvS + k] = k <= 200 ? re[4 * c + e] * re[4 * c + e] + im[4 * c + e] * im[4 * c + e] : 0.f;
         }
     }
   }
@@ -313,7 +297,7 @@ __global__ __launch_bounds__(256) void k_logmel_frames_mfma(const float* __restr
   }
   __syncthreads();
   // log10 in fp64, rounded once (see the VALU kernel), spread over all 256 threads
-  for (int i = tid; i < kNmel * kMT; i += 256) {
+  for (int i = tid; i < kNmel * kMT; i += kMThreads) {
     const int m = i >> 5, f = i & 31;
     const float lg = (float)log10((double)fmaxf(tile[m * 33 + f], 1e-10f));
     tile[m * 33 + f] = lg;
@@ -323,11 +307,12 @@ __global__ __launch_bounds__(256) void k_logmel_frames_mfma(const float* __restr
   if (lane == 0) red[wave] = lmax;
   __syncthreads();
   if (tid == 0) {
-    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float m = red[0];
+    for (int w = 1; w < kMThreads / 64; ++w) m = fmaxf(m, red[w]);
     if (m > -INFINITY) atomicMax(&seg_max[seg], fkey(m));
   }
   // whole 128-byte runs of a mel row per store instruction
-  for (int i = tid; i < kNmel * kMT; i += 256) {
+  for (int i = tid; i < kNmel * kMT; i += kMThreads) {
     const int m = i >> 5, f = i & 31;
     if (t0 + f < live) out[((long)seg * kNmel + m) * kFrames + t0 + f] = tile[m * 33 + f];
   }
@@ -454,7 +439,7 @@ extern "C" int gww_logmel_f32(gww_frontend* fe, const float* wave, int n_seg, in
                        reinterpret_cast<unsigned int*>(seg_max));
   } else {
     dim3 g1((unsigned)cdiv(live, kMT), (unsigned)n_seg);
-    hipLaunchKernelGGL(k_logmel_frames_mfma, g1, dim3(256), 0, s, wave, wave_stride, n_eff, live, fe->tb, out,
+    hipLaunchKernelGGL(k_logmel_frames_mfma, g1, dim3(kMThreads), 0, s, wave, wave_stride, n_eff, live, fe->tb, out,
                        reinterpret_cast<unsigned int*>(seg_max));
   }
   GWW_LAUNCH_CHECK();
