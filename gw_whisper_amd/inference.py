@@ -163,20 +163,23 @@ class DeviceSegmentSlicer:
 
 def evaluate_slices(slicer: DeviceSegmentSlicer, network: nn.Module, device: str = "cuda",
                     trigger_threshold: float = 0.2, verbose: bool = False,
-                    batch_size: int = 256) -> Tuple[List[List[float]], List[np.ndarray]]:
+                    batch_size: int = 256, window_range: Optional[Tuple[int, int]] = None
+                    ) -> Tuple[List[List[float]], List[np.ndarray]]:
     """Reference ``evaluate_slices`` (``inference.py:454-489``): run ``network`` over all windows in batches of 256,
     keep ``outputs[:, 0]`` as the signal score, return ``([[time, score], ...] above threshold, [scores per batch])``.
     Scores and times stay on the device; the threshold is one comparison + ``nonzero`` and everything leaves the
-    GPU in two copies per segment instead of one ``.item()`` per window."""
-    n = len(slicer)
+    GPU in two copies per segment instead of one ``.item()`` per window.  ``window_range``: evaluate only windows
+    ``[w0, w1)`` (a rank's batch-aligned shard)."""
+    w0, w1 = (0, len(slicer)) if window_range is None else window_range      # one rank's shard (shard_windows)
+    n = w1 - w0
     scores = torch.empty((n,), dtype=torch.float32, device=slicer.dss.device)
     with torch.no_grad():
         for i0 in range(0, n, batch_size):
             i1 = min(n, i0 + batch_size)
-            out = network(slicer.windows(i0, i1).contiguous())
+            out = network(slicer.windows(w0 + i0, w0 + i1).contiguous())
             scores[i0:i1] = out[:, 0].to(torch.float32)
         keep = torch.nonzero(scores > trigger_threshold).flatten()
-        times = slicer.times(0, n)
+        times = slicer.times(w0, w1)
         trig = torch.stack((times[keep], scores[keep].to(torch.float64)), dim=1).cpu().numpy()
         all_scores = scores.cpu().numpy()
     new_triggers = [[float(t), float(s)] for t, s in trig]

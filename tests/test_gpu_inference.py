@@ -83,3 +83,67 @@ def test_device_slicer_pipeline_equals_per_window_evaluation(T, gww):
     assert len(trig) == len(ref)
     if ref:
         np.testing.assert_allclose(np.array(trig), np.array(ref), atol=1e-6)
+
+
+def test_sharded_window_ranges_reproduce_the_full_evaluation(T, gww):
+    """the batch-aligned shards of two ranks, concatenated in rank order, are the single-process
+    result (scores and triggers)."""
+    from gw_whisper_amd import inference as inf
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    rng = np.random.default_rng(4)
+    strain = rng.standard_normal((2, 2048 + 204 * 22)).astype(np.float32)
+    sd = synth.encoder_state_dict(128, 2, 2, 512, seed=3)
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig(128, 2, 2, 512), precision="bf16").cuda()
+    model = inf.GWWhisperClassifier(enc).cuda().eval()
+    sl = inf.DeviceSegmentSlicer(strain, start_time=5.0)
+    trig, vals = inf.evaluate_slices(sl, model, trigger_threshold=0.5, batch_size=4)
+    parts = [inf.evaluate_slices(sl, model, trigger_threshold=0.5, batch_size=4,
+                                 window_range=inf.shard_windows(len(sl), r, 2, 4)) for r in range(2)]
+    np.testing.assert_array_equal(np.concatenate(vals), np.concatenate([v for p in parts for v in p[1]]))
+    assert trig == [x for p in parts for x in p[0]]
+
+
+def test_run_inference_harness_end_to_end(T, gww, tmp_path):
+    """harness/run_inference.py (counterpart of MLGWSC-1/inference.py main): .npz segments in the reference's layout
+    -> Q-adapter -> DoRA-wrapped whisper-tiny -> scores -> clustered triggers, equal to the same pipeline assembled by
+    hand; --white is mandatory and an existing output needs --force."""
+    import importlib.util
+    from gw_whisper_amd import inference as inf
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_inference", os.path.join(root, "harness", "run_inference.py"))
+    ri = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ri)
+    rng = np.random.default_rng(9)
+    segs = {"1000": rng.standard_normal((2, 2048 + 204 * 9)).astype(np.float32),
+            "2000": rng.standard_normal((2, 2048 + 204 * 4 + 50)).astype(np.float32)}
+    arrays = {}
+    for key, x in segs.items():
+        arrays[f"H1/{key}"], arrays[f"L1/{key}"] = x[0], x[1]
+        arrays[f"{key}/start_time"], arrays[f"{key}/delta_t"] = float(key), 1.0 / 2048
+    src, dst = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    np.savez(src, **arrays)
+    argv = [src, dst, "--white", "--trigger-threshold=-1e9", "--batch-size", "4", "--debug-triggers-file", str(tmp_path / "trig.npz")]
+    with pytest.raises(SystemExit):
+        ri.main([src, dst])                                   # no --white
+    assert ri.main(argv) == 0
+    with pytest.raises(RuntimeError):
+        ri.main(argv)                                         # exists, no --force
+    out = np.load(dst)
+    assert out["all_vals"].shape == (10 + 5,) and np.isfinite(out["all_vals"]).all()
+    # by hand: same seeded model, longest segment first
+    args = ri.parse_args(argv)
+    model = ri.build_model(args, T.device("cuda"))
+    ref_vals, ref_trig = [], {}
+    for key in ("1000", "2000"):
+        sl = inf.DeviceSegmentSlicer(segs[key], start_time=float(key), key=key)
+        trig, vals = inf.evaluate_slices(sl, model, trigger_threshold=-1e9, batch_size=4)
+        ref_trig[key] = trig
+        ref_vals += vals
+    np.testing.assert_allclose(out["all_vals"], np.concatenate(ref_vals), atol=2e-3)
+    t_ref, s_ref, v_ref = inf.get_clusters(ref_trig, 0.35)
+    np.testing.assert_allclose(out["time"], t_ref, atol=1e-6)
+    np.testing.assert_allclose(out["stat"], s_ref, atol=2e-3)
+    assert (out["var"] == 0.2).all() and len(out["time"]) >= 1
+    dbg = np.load(str(tmp_path / "trig.npz"))
+    assert dbg["1000"].shape == (10, 2) and dbg["2000"].shape == (5, 2)
