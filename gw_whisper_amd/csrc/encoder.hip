@@ -568,10 +568,28 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
       pending = d2;
     }
   } else {
+    // only the last token wanted (bf16 generic path, e.g. whisper-small): same pooled last layer as above
+    const bool pooled_g = bf && !last_hidden && last_token && T >= 3 && !(generic_mask & 32);
     for (int i = 0; i < e->cfg.n_layers; ++i) {
       const LayerW& L = e->layers[i];
       TR(TR_LN, launch_layernorm(x, L.ln1w, L.ln1b, h, bf ? 1 : 0, M, d, s));
       TR(TR_QKV, gemm(h, d, L.wqkv, L.wqkv32, L.bqkv, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0));
+      if (pooled_g && i == e->cfg.n_layers - 1) {
+        TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s, nullptr, /*last_tile_only=*/true));
+        float* xs2 = (float*)(base + w.x2);    // [B, d] x rows (b, T-1) | x_mid | layer output
+        float* xl = xs2;
+        float* xm = xs2 + (size_t)B * d;
+        float* xf = xs2 + 2 * (size_t)B * d;
+        GWW_HIP(hipMemcpy2DAsync(xl, (size_t)d * 4, x + (size_t)(T - 1) * d, (size_t)T * d * 4, (size_t)d * 4, B,
+                                 hipMemcpyDeviceToDevice, s));
+        TR(TR_OUT, launch_gemm_bf16((const unsigned short*)ctx + (size_t)(T - 1) * d, (long)T * d, L.wo, L.bo, xl, nullptr,
+                                    xm, B, d, d, EPI_RESID, 0, s, 0));
+        TR(TR_LN, launch_layernorm(xm, L.ln2w, L.ln2b, h, 1, B, d, s));
+        TR(TR_FC1, launch_gemm_bf16(h, d, L.w1, L.b1, nullptr, nullptr, f1, B, F, d, EPI_GELU, 0, s, 0));
+        TR(TR_FC2, launch_gemm_bf16(f1, F, L.w2, L.b2, xm, nullptr, xf, B, d, F, EPI_RESID, 0, s, 0));
+        TR(TR_LN, launch_layernorm_rows(xf, d, e->lnw, e->lnb, last_token, B, d, s, nullptr));
+        return GWW_OK;
+      }
       if (bf) TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s));
       else TR(TR_ATTN, launch_attention_f32((const float*)qkv, (float*)ctx, B, T, H, s));
       TR(TR_OUT, gemm(ctx, d, L.wo, L.wo32, L.bo, x, nullptr, x, M, d, d, EPI_RESID, 0));

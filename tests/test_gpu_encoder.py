@@ -209,7 +209,7 @@ def test_dual_stream_split_is_bit_identical(T, gww):
     assert T.equal(a_h, b_h) and T.equal(a_l, b_l)
 
 
-@pytest.mark.parametrize("name,B", [("tiny", 5), ("base", 2)])
+@pytest.mark.parametrize("name,B", [("tiny", 5), ("base", 2), ("small", 2)])
 def test_pooled_forward_equals_last_row_of_full_forward(T, gww, name, B):
     """``encoder.last_token`` (bf16): the last layer runs on the B last-token rows only (attention for the one
     query tile holding token 1499, row-wise ops on B rows) -- the same function as ``last_hidden_state[:, -1]``
