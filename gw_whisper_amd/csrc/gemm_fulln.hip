@@ -184,6 +184,18 @@ __global__ __launch_bounds__(512, 1) void k_gemm_fulln(const unsigned short* __r
     constexpr int STRIDE = (HALF + 4) * 4;              // bytes per staged fp32 half row
     static_assert(FN_BM * STRIDE <= FN_NST * STAGE, "staging does not fit the ring");
     float* Cf = reinterpret_cast<float*>(C);
+    // output row and position row of each of the 128 tile rows, computed ONCE (one 64-bit division per row instead of
+    // one per 16-byte chunk in the copy loops below): dst_row = b * valid + t, or -1 for the per-batch garbage row
+    int* row_dst = reinterpret_cast<int*>(lds + FN_BM * STRIDE);          // [128] after the staged half tile
+    int* row_t = row_dst + FN_BM;
+    static_assert(FN_BM * STRIDE + 2 * FN_BM * 4 <= FN_NST * STAGE, "row table does not fit the ring");
+    if (tid < FN_BM) {
+      const long m = m0 + tid;
+      const long b = m / rows_per_batch;
+      const int t = (int)(m - b * rows_per_batch);
+      row_t[tid] = t;
+      row_dst[tid] = (m < M && t < valid_rows) ? (int)(b * valid_rows + t) : -1;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if ((wn >> 1) == h) {
@@ -204,14 +216,12 @@ __global__ __launch_bounds__(512, 1) void k_gemm_fulln(const unsigned short* __r
       constexpr int CPR = HALF / 4;                     // float4 chunks per half row
       for (int idx = tid; idx < FN_BM * CPR; idx += 512) {
         const int row = idx / CPR, ch = idx - row * CPR;
-        const long m = m0 + row;
-        const long b = m / rows_per_batch;
-        const int t = (int)(m - b * rows_per_batch);
-        if (m < M && t < valid_rows) {
+        const int dst = row_dst[row];
+        if (dst >= 0) {
           float4 v = *reinterpret_cast<const float4*>(lds + row * STRIDE + ch * 16);
-          const float4 p = *reinterpret_cast<const float4*>(pos + (long)t * N + h * HALF + ch * 4);
+          const float4 p = *reinterpret_cast<const float4*>(pos + (long)row_t[row] * N + h * HALF + ch * 4);
           v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-          *reinterpret_cast<float4*>(Cf + (b * valid_rows + t) * N + h * HALF + ch * 4) = v;
+          *reinterpret_cast<float4*>(Cf + (long)dst * N + h * HALF + ch * 4) = v;
         }
       }
       __syncthreads();
