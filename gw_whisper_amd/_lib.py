@@ -111,6 +111,8 @@ SIGNATURES = {
     "gww_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
 }
 
+ABI_VERSION = 101   # include/gww.h GWW_VERSION this binding was written against
+
 _lib = None
 
 
@@ -136,6 +138,10 @@ def lib():
         fn = getattr(handle, name)   # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # a stale build with the same symbol names but older argument lists would be called with the wrong ABI
+    if handle.gww_version() < ABI_VERSION:
+        raise GwwError(f"{LIB_PATH} reports ABI {handle.gww_version()}, this package needs {ABI_VERSION}: rebuild it "
+                       "(`make -C gw_whisper_amd/csrc`)")
     _lib = handle
     return _lib
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GWW_VERSION 100  /* 0.1.0 */
+#define GWW_VERSION 101  /* 0.1.1: pooled training entry points, gww_dora_grads_multi, gww_attention_log2q_bf16 */
 
 #define GWW_OK 0
 #define GWW_ERR_ARG (-1)      /* bad argument (shape, null pointer, unsupported size) */
