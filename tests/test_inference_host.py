@@ -1,6 +1,7 @@
 """Host-side logic of the search pipeline (gw_whisper_amd/inference.py) against restatements of the reference's
 MLGWSC-1/inference.py and train.py; runs on CPU."""
 import numpy as np
+import pytest
 import torch
 
 from gw_whisper_amd import inference as inf
@@ -111,3 +112,39 @@ def test_resample_matrix_is_scipy_resample():
     R = inf.resample_matrix(2048, 16000).astype(np.float64)
     x = np.random.default_rng(4).standard_normal((3, 2048))
     np.testing.assert_allclose(x @ R.T, resample(x, 16000, axis=1), atol=5e-6)
+
+
+def test_run_inference_harness_host_side(tmp_path):
+    """harness/run_inference.py without a GPU: the reference's argument surface, the segment file layout
+    (``/<detector>/<key>`` + start_time / delta_t), the result writer, and the two refusals that need no device."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_inference", os.path.join(root, "harness", "run_inference.py"))
+    ri = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ri)
+    a = ri.parse_args(["in.hdf", "out.hdf", "--white", "--lora-weights", "L", "--dense-weights", "D",
+                       "--adapter-weights", "A", "--trigger-threshold=-0.5", "--step-size", "0.1"])
+    assert (a.inputfile, a.outputfile, a.white, a.softmax) == ("in.hdf", "out.hdf", True, False)
+    assert a.cluster_threshold == 0.35 and a.trigger_threshold == -0.5 and a.device == "cuda"
+    rng = np.random.default_rng(0)
+    arrays = {}
+    for key, n in (("100", 5000), ("200", 3000)):
+        for d in ri.DETECTORS:
+            arrays[f"{d}/{key}"] = rng.standard_normal(n).astype(np.float32)
+        arrays[f"{key}/start_time"], arrays[f"{key}/delta_t"] = float(key), 1.0 / 2048
+    src = str(tmp_path / "in.npz")
+    np.savez(src, **arrays)
+    segs = ri.read_segments(src)
+    assert sorted(segs) == ["100", "200"]
+    x, st, dt = segs["200"]
+    assert x.shape == (2, 3000) and st == 200.0 and dt == 1.0 / 2048
+    np.testing.assert_array_equal(x[1], arrays["L1/200"])
+    out = str(tmp_path / "res.npz")
+    ri.write_result(out, {"time": np.array([1.5]), "stat": np.array([0.9]), "var": np.array([0.2])})
+    z = np.load(out)
+    assert z["time"][0] == 1.5 and z["var"][0] == 0.2
+    with pytest.raises(SystemExit):
+        ri.main([src, str(tmp_path / "o.npz")])                       # whitening is not part of this build
+    with pytest.raises(RuntimeError):
+        ri.main([src, out, "--white"])                                 # output exists, no --force
