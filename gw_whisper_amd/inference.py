@@ -15,9 +15,9 @@ step), the threshold is applied on the device and triggers leave the GPU in one 
     ResampleMelAdapter            the reference's OTHER front end (Signal_vs_Noise/utils/preprocess.py:44-51 +
                                   WhisperFeatureExtractor): FFT resampling 2048 -> 16000 Hz and log-mel, on device
 
-Whitening (PyCBC, :56-137) and the HDF5 reader stay host-side reference code.
-The Q-transform adapter (``ml4gw.QScan``, absent upstream source) is not built: ``GWWhisperClassifier`` takes any
-adapter mapping ``[B, D, 2048] -> [B, D, 80, 3000]``.
+Whitening (PyCBC, :56-137): ``whiten.py``.  The HDF5 reader stays host-side reference code.
+The Q-transform adapter of the reference (``QTransformAdapter``, both the train.py and the inference.py variant) is
+``qscan.QTransformAdapter``; ``GWWhisperClassifier`` takes any adapter mapping ``[B, D, 2048] -> [B, D, 80, 3000]``.
 """
 
 from __future__ import annotations
@@ -125,9 +125,12 @@ def remove_softmax_from_classifier(model: GWWhisperClassifier) -> None:
 class DeviceSegmentSlicer:
     """Overlapping windows of multi-detector (already whitened) strain, as strided views of ONE device tensor.
 
-    Same indexing as the reference ``SegmentSlicer`` with ``white=True`` (``inference.py:173-262``):
-    ``index_step_size = int(step_size / delta_t)``, window i covers samples ``[i * step, i * step + slice_length)``
-    and is stamped ``start_time + i * delta_t * step + peak_offset``."""
+    Same indexing and time stamps as the reference ``SegmentSlicer`` with ``white=True`` (``inference.py:173-264``):
+    ``delta_t = 1 / (1 / attrs["delta_t"])``, ``index_step_size = int(step_size / delta_t)``, window i covers samples
+    ``[i * step, i * step + slice_length)``.  The reference stamps window i with a RUNNING float64 sum
+    (``current_time += time_step_size``, ``:262-263``), not with ``start + i * step``: the two differ in the last
+    bits and ``get_clusters`` thresholds on time differences, so ``times()`` reproduces the running sum exactly
+    (``np.add.accumulate`` is the same sequence of float64 additions), once per segment on the host."""
 
     def __init__(self, strain, start_time: float = 0.0, delta_t: float = 1.0 / 2048, step_size: float = 0.1,
                  peak_offset: float = 0.6, slice_length: int = 2048, key: str = "segment", device="cuda"):
@@ -136,14 +139,15 @@ class DeviceSegmentSlicer:
             raise ValueError("strain must be [detectors, samples]")
         self.dss = t.to(device=device, dtype=torch.float32).contiguous()       # the ONE host-to-device copy
         self.key = key
-        self.start_time = float(start_time)
-        self.delta_t = float(delta_t)
+        self.start_time = start_time
+        self.delta_t = 1.0 / (1.0 / delta_t)          # the reference's double inversion (:196), kept bit for bit
         self.step_size = step_size
         self.peak_offset = peak_offset
         self.slice_length = slice_length
         self.index_step_size = int(self.step_size / self.delta_t)
         self.time_step_size = self.delta_t * self.index_step_size
         self.white = True
+        self._time_table = None
 
     def __len__(self) -> int:
         n = self.dss.shape[1]
@@ -156,9 +160,16 @@ class DeviceSegmentSlicer:
         base = self.dss[:, i0 * self.index_step_size:]
         return base.as_strided((n, D, self.slice_length), (self.index_step_size, self.dss.stride(0), 1))
 
+    def times_host(self, i0: int, i1: int) -> np.ndarray:
+        """float64 time stamps of windows i0..i1-1, bit-identical to the reference iterator's."""
+        if self._time_table is None or len(self._time_table) != len(self):
+            steps = np.full((max(len(self), 1),), self.time_step_size, dtype=np.float64)
+            steps[0] = self.start_time
+            self._time_table = np.add.accumulate(steps)        # t_0 = start, t_i = t_(i-1) + step: sequential adds
+        return self._time_table[i0:i1] + self.peak_offset
+
     def times(self, i0: int, i1: int) -> torch.Tensor:
-        idx = torch.arange(i0, i1, device=self.dss.device, dtype=torch.float64)
-        return self.start_time + idx * self.time_step_size + self.peak_offset
+        return torch.from_numpy(self.times_host(i0, i1)).to(self.dss.device)
 
 
 def evaluate_slices(slicer: DeviceSegmentSlicer, network: nn.Module, device: str = "cuda",

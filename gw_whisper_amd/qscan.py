@@ -156,25 +156,59 @@ class QScan(nn.Module):
 
 
 class QTransformAdapter(nn.Module):
-    """Reference ``MLGWSC-1/train.py:78-154`` (same constructor arguments, parameter names and forward)."""
+    """The reference's Q-transform adapter, both variants, same constructor arguments, parameter names and forward:
+
+    * ``MLGWSC-1/train.py:78-154``  -- ``spectrogram_shape=[128, 128]``, CNN channels 1 -> 32 -> 64 -> 128 -> 1
+      (the defaults here, ``QTransformAdapter.train_variant``);
+    * ``MLGWSC-1/inference.py:303-351`` -- ``spectrogram_shape=[512, 512]``, channels 1 -> 16 -> 32 -> 64 -> 1
+      (``QTransformAdapter.inference_variant``; ``build_model`` :425-426 loads its ``state_dict``).
+
+    ``channels`` is the one argument the reference does not have (it hard-codes the widths per file);
+    ``from_state_dict`` picks the variant from a checkpoint's tensor shapes."""
+
+    TRAIN_CHANNELS = (32, 64, 128)
+    INFERENCE_CHANNELS = (16, 32, 64)
 
     def __init__(self, kernel_length: float = 1.0, sample_rate: int = 2048, q_range: List[int] = [4, 128],
                  spectrogram_shape: List[int] = [128, 128], target_shape: Tuple[int, int] = (80, 3000),
-                 n_detectors: int = 2):
+                 n_detectors: int = 2, channels: Sequence[int] = TRAIN_CHANNELS):
         super().__init__()
         self.n_detectors = n_detectors
+        self.target_shape = tuple(int(v) for v in target_shape)
         self.q_transform = QScan(duration=kernel_length, sample_rate=sample_rate, spectrogram_shape=spectrogram_shape,
                                  qrange=q_range)
+        c1, c2, c3 = (int(c) for c in channels)
         self.freq_adapter = nn.Sequential(
-            nn.Conv2d(1, 32, 3, padding=1), nn.ReLU(), nn.MaxPool2d(2),
-            nn.Conv2d(32, 64, 3, padding=1), nn.ReLU(), nn.MaxPool2d(2),
-            nn.Conv2d(64, 128, 3, padding=1), nn.ReLU(),
-            nn.Conv2d(128, 1, 1))
-        self.final_pool = nn.AdaptiveAvgPool2d(target_shape)
+            nn.Conv2d(1, c1, 3, padding=1), nn.ReLU(), nn.MaxPool2d(2),
+            nn.Conv2d(c1, c2, 3, padding=1), nn.ReLU(), nn.MaxPool2d(2),
+            nn.Conv2d(c2, c3, 3, padding=1), nn.ReLU(),
+            nn.Conv2d(c3, 1, 1))
+        self.final_pool = nn.AdaptiveAvgPool2d(self.target_shape)
         self.scale = nn.Parameter(torch.ones(1))
         self.bias = nn.Parameter(torch.zeros(1))
         self.film_gamma = nn.Parameter(torch.ones(self.n_detectors))
         self.film_beta = nn.Parameter(torch.zeros(self.n_detectors))
+
+    @classmethod
+    def train_variant(cls, **kw) -> "QTransformAdapter":
+        return cls(spectrogram_shape=[128, 128], channels=cls.TRAIN_CHANNELS, **kw)
+
+    @classmethod
+    def inference_variant(cls, **kw) -> "QTransformAdapter":
+        return cls(spectrogram_shape=[512, 512], channels=cls.INFERENCE_CHANNELS, **kw)
+
+    @classmethod
+    def from_state_dict(cls, sd: dict, spectrogram_shape=None, **kw) -> "QTransformAdapter":
+        """Build the variant a checkpoint was saved from (channel widths read off ``freq_adapter.{0,3,6}.weight``;
+        the Q-scan resolution is not stored in a ``state_dict``: it defaults to the one the reference pairs with the
+        widths -- 128 x 128 for 32/64/128, 512 x 512 for 16/32/64) and load it."""
+        ch = tuple(int(sd[f"freq_adapter.{i}.weight"].shape[0]) for i in (0, 3, 6))
+        if spectrogram_shape is None:
+            spectrogram_shape = [512, 512] if ch == cls.INFERENCE_CHANNELS else [128, 128]
+        kw.setdefault("n_detectors", int(sd["film_gamma"].shape[0]))
+        m = cls(spectrogram_shape=spectrogram_shape, channels=ch, **kw)
+        m.load_state_dict(sd)
+        return m
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, D, _ = x.shape

@@ -128,9 +128,13 @@ def build_model(args, device):
     else:
         targets = [n for n, _ in encoder.named_modules() if n.endswith(("q_proj", "k_proj", "v_proj"))]
         encoder = get_peft_model(encoder, LoraConfig(use_dora=True, r=8, lora_alpha=32, target_modules=targets))
-    adapter = QTransformAdapter(n_detectors=len(DETECTORS))
+    # the inference.py variant of the adapter (512 x 512 Q-scan, channels 16 / 32 / 64; inference.py:303-337) unless the
+    # checkpoint was saved from the train.py variant (train.py:78-133): the variant is read off its tensor shapes
     if args.adapter_weights:
-        adapter.load_state_dict(torch.load(args.adapter_weights, map_location="cpu"))
+        adapter = QTransformAdapter.from_state_dict(torch.load(args.adapter_weights, map_location="cpu"),
+                                                    n_detectors=len(DETECTORS))
+    else:
+        adapter = QTransformAdapter.inference_variant(n_detectors=len(DETECTORS))
     model = inf.GWWhisperClassifier(whisper_encoder=encoder, n_detectors=len(DETECTORS), adapter=adapter)
     if args.dense_weights:
         model.classifier.load_state_dict(torch.load(args.dense_weights, map_location="cpu"))

@@ -158,7 +158,7 @@ int gww_dora_merge_f32(const float* w0, const float* a, const float* b, const fl
  * -------------------------------------------------------------------------- */
 typedef struct {
   int layer;            /* encoder layer index */
-  int proj;             /* 0 q_proj, 1 k_proj, 2 v_proj (3 out_proj: not implemented yet) */
+  int proj;             /* 0 q_proj, 1 k_proj, 2 v_proj, 3 out_proj */
   int r;                /* LoRA rank (8) */
   float scaling;        /* lora_alpha / r */
   const float* A;       /* [r, d]   lora_A.weight */
@@ -265,8 +265,9 @@ int gww_gemm_f32(const float* A, const float* W, const float* bias, const float*
 /* softmax(q k^T) v per head, q pre-scaled; qkv [B,T,3*d] (q|k|v), ctx [B,T,d]; head_dim 64 */
 int gww_attention_bf16(const void* qkv, void* ctx, int B, int T, int n_heads, void* stream);
 int gww_attention_f32(const float* qkv, float* ctx, int B, int T, int n_heads, void* stream);
-/* the software-pipelined bf16 kernel the encoder's fast path launches: q must be in log2 units, i.e. projected with
- * log2(e) / 8 instead of 1 / 8 (gww_encoder_set_weights folds that into the packed q panel); lse optional, natural log */
+/* experimental software-pipelined bf16 kernel (off by default; the encoder launches it only under GWW_ATT_PIPE=1):
+ * q must be in log2 units, i.e. projected with log2(e) / 8 instead of 1 / 8 (gww_encoder_set_weights folds that into
+ * the packed q panel when the switch is on); lse optional, natural log */
 int gww_attention_log2q_bf16(const void* qkv, void* ctx, float* lse_or_null, int B, int T, int n_heads, void* stream);
 /* attention backward: dqkv [B,T,3d] from qkv, ctx (forward output), dctx and the forward's lse [B,H,T]
  * (gww_attention_lse_bf16 below); d_scratch: B * H * (T + ceil(T / 64)) fp32 words (row dots + live-tile flags:

@@ -256,3 +256,79 @@ def test_named_sizes_match_oracle(T, gww, name):
     e16 = np.abs(out16 - ref).max()
     print(f"[{name}] bf16 max |hidden - oracle| = {e16:.3e} (|hidden| max {np.abs(ref).max():.2f})")
     assert e16 < 0.15 and np.abs(out16 - ref).mean() < 6e-3
+
+
+def _config4_segments():
+    n = 12
+    seg = synth.strain_segments(n, seed=44)
+    t = np.arange(16000, dtype=np.float32) / 16000.0
+    for i in range(n):      # same construction as tools/make_golden.py::make_config4
+        amp = 0.5 * (400.0 ** (i / (n - 1)))
+        seg[i] += (amp * np.sin(2 * np.pi * (30.0 + 35.0 * i) * t) * np.exp(-((t - 0.1 - 0.07 * i) / 0.03) ** 2)).astype(np.float32)
+    return seg
+
+
+@pytest.mark.parametrize("precision,tol_last", [("fp32", 5e-4), ("bf16", 8e-2)])
+def test_config4_glitch_classifier_against_reference_golden(T, gww, golden, precision, tol_last):
+    """BASELINE config 4 through the log-mel front end the reference's Glitch code uses
+    (Glitch_classification/src/dataset.py:46): whisper-base, the 22-class head of
+    Glitch_classification/src/model.py:10-38 (golden: that very file on an HF whisper-base encoder,
+    tools/make_golden.py::make_config4).  ``models.glitch_classifier`` on the GPU: logits within 1e-3, argmax labels
+    exact."""
+    from gw_whisper_amd import ops
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    from gw_whisper_amd.models import glitch_classifier
+    g = golden("config4.npz")
+    d, L, H, F = synth.ENCODER_SIZES["base"]
+    sd = synth.encoder_state_dict(d, L, H, F, seed=4)
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig.named("base"), precision=precision)
+    model = glitch_classifier(enc, num_classes=22)
+    head = synth.head_state_dict([d, 512, 256, 128, 22], seed=769, sequential_stride=3)
+    head["9.bias"] = head["9.bias"] + g["class_bias_shift"]
+    model.classifier.load_state_dict({k: T.from_numpy(v) for k, v in head.items()})   # keys 0 / 3 / 6 / 9: Dropout slots
+    model = model.cuda().eval()
+    mel = ops.logmel(T.from_numpy(_config4_segments()).cuda())
+    with T.no_grad():
+        last = enc.last_token(mel).cpu().numpy()
+        logits = model(mel).cpu().numpy()
+        hidden_last = enc(mel).last_hidden_state[:, -1, :].cpu().numpy()
+    err_last = np.abs(last - g["last_token"]).max()
+    err = np.abs(logits - g["logits"]).max()
+    print(f"[config 4, {precision}] max |last_token - HF| = {err_last:.3e}, max |logit - reference| = {err:.3e}, "
+          f"smallest top-2 margin of the golden = {g['top2_margin'].min():.3e}")
+    assert logits.shape == (12, 22)
+    assert err_last < tol_last
+    np.testing.assert_allclose(hidden_last, last, atol=1e-6 if precision == "fp32" else 2e-2)
+    assert err < 1e-3
+    np.testing.assert_array_equal(logits.argmax(1), g["labels"])
+    assert len(set(g["labels"].tolist())) >= 4
+
+
+def test_tiny_batch_256_rows_equal_the_batch_64_rows(T, gww, golden):
+    """BASELINE config 2 shape (B = 256): every segment's output is independent of the batch it rides in -- rows of
+    a B = 256 whisper-tiny bf16 forward are bit-equal to the same rows of four B = 64 calls -- and the first 64
+    (config 1's H1 segments) still hit the reference golden."""
+    from gw_whisper_amd import ops
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    g = golden("config1.npz")
+    sd = synth.named_encoder_state_dict("tiny", seed=0)
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig.named("tiny"), precision="bf16").cuda()
+    h1 = synth.strain_segments(64, seed=0)
+    t = np.arange(16000, dtype=np.float32) / 16000.0
+    for i in range(0, 64, 2):
+        h1[i] += (3.0 * np.sin(2 * np.pi * (40.0 + 200.0 * t * (1 + 0.05 * i)) * t) * np.exp(-((t - 0.6) / 0.15) ** 2)).astype(np.float32)
+    wave = np.concatenate([h1, synth.strain_segments(192, seed=5)])
+    mel = ops.logmel(T.from_numpy(wave).cuda())
+    with T.no_grad():
+        big_h, big_l = enc.forward_raw(mel, want_hidden=True, want_last=True)
+        pooled = enc.last_token(mel)
+        for q in range(4):
+            h, l = enc.forward_raw(mel[64 * q:64 * (q + 1)], want_hidden=True, want_last=True)
+            assert T.equal(big_h[64 * q:64 * (q + 1)], h), f"hidden rows of quarter {q} depend on the batch"
+            assert T.equal(big_l[64 * q:64 * (q + 1)], l)
+            assert T.equal(pooled[64 * q:64 * (q + 1)], enc.last_token(mel[64 * q:64 * (q + 1)]))
+    assert T.equal(big_h[:, -1, :], big_l)
+    err = np.abs(big_l[:64].cpu().numpy() - g["last_token"][:, 0]).max()
+    print(f"B = 256: max |last_token[:64] - HF golden| = {err:.3e}")
+    assert err < 8e-2
+    assert (pooled - big_l).abs().max().item() < 2e-2

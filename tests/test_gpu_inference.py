@@ -147,3 +147,66 @@ def test_run_inference_harness_end_to_end(T, gww, tmp_path):
     assert (out["var"] == 0.2).all() and len(out["time"]) >= 1
     dbg = np.load(str(tmp_path / "trig.npz"))
     assert dbg["1000"].shape == (10, 2) and dbg["2000"].shape == (5, 2)
+
+
+def test_config5_small_q_adapter_search_matches_oracle_pipeline(T, gww):
+    """BASELINE config 5 composition: whisper-small + QTransformAdapter (the inference.py variant: 512 x 512 Q-scan,
+    channels 16 / 32 / 64, MLGWSC-1/inference.py:303-351) + GWWhisperClassifier through DeviceSegmentSlicer /
+    evaluate_slices on a short two-detector segment.  Scores against the oracle pipeline (oracle Q-scan -> the same
+    CNN in fp64 on the CPU -> oracle whisper-small -> head), and sharded == unsharded bit for bit."""
+    from gw_whisper_amd import inference as inf, synth
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    from gw_whisper_amd.qscan import QTransformAdapter
+    from oracle import encoder as oenc, heads as oheads, qscan as oq
+    T.manual_seed(3)
+    d, L, H, F = synth.ENCODER_SIZES["small"]
+    sd = synth.encoder_state_dict(d, L, H, F, seed=9)
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig.named("small"), precision="bf16")
+    adapter = QTransformAdapter.inference_variant(n_detectors=2)
+    with T.no_grad():
+        adapter.film_gamma.copy_(T.tensor([1.3, 0.8]))
+        adapter.film_beta.copy_(T.tensor([0.05, -0.1]))
+        adapter.scale.fill_(0.7)
+        adapter.bias.fill_(-0.2)
+    model = inf.GWWhisperClassifier(enc, n_detectors=2, num_classes=2, adapter=adapter)
+    head = synth.head_state_dict([2 * d, 512, 256, 128, 64, 2], seed=11)
+    model.classifier.load_state_dict({k: T.from_numpy(v) for k, v in head.items()}, strict=True)
+    model = model.cuda().eval()
+    n_win = 6
+    strain = synth.strain_segments(2, seed=91, n_samples=2048 + (n_win - 1) * 204)
+    t = np.arange(strain.shape[1]) / 2048.0
+    strain += (6.0 * np.sin(2 * np.pi * (60 + 90 * t) * t) * np.exp(-((t - 0.9) / 0.12) ** 2)).astype(np.float32)
+    sl = inf.DeviceSegmentSlicer(strain, start_time=10.0)
+    assert len(sl) == n_win
+    trig, vals = inf.evaluate_slices(sl, model, trigger_threshold=0.0, batch_size=2)
+    scores = np.concatenate(vals)
+    assert scores.shape == (n_win,) and np.isfinite(scores).all() and len(trig) == n_win
+    # sharded: two ranks, batch-aligned window ranges -> identical batches -> identical bits
+    parts = []
+    for r in range(2):
+        w0, w1 = inf.shard_windows(n_win, r, 2, batch_size=2)
+        parts.append(np.concatenate(inf.evaluate_slices(sl, model, trigger_threshold=0.0, batch_size=2,
+                                                        window_range=(w0, w1))[1]))
+    np.testing.assert_array_equal(np.concatenate(parts), scores)
+
+    # ---- oracle pipeline, batch by batch (the Q plane is chosen per batch and detector, as the product does)
+    cnn = T.nn.Sequential(*[m for m in adapter.freq_adapter]).cpu().double()
+    ref = []
+    for b0 in range(0, n_win, 2):
+        win = np.stack([strain[:, (b0 + j) * 204:(b0 + j) * 204 + 2048] for j in range(2)])       # [2, D, 2048]
+        toks = []
+        for det in range(2):
+            q = oq.qscan(win[:, det], spectrogram_shape=(512, 512), qrange=(4, 128))               # [2, 512, 512]
+            with T.no_grad():
+                y = cnn(T.from_numpy(q)[:, None])
+                y = T.nn.functional.adaptive_avg_pool2d(y, (80, 3000))[:, 0]
+                y = (0.7 * y - 0.2) * float(adapter.film_gamma[det]) + float(adapter.film_beta[det])
+            hidden = oenc.encoder_forward(sd, y.numpy().astype(np.float32), oenc.EncCfg(d, L, H, F), dtype=np.float32)
+            toks.append(hidden[:, -1, :])
+        logits = oheads.mlp(np.concatenate(toks, axis=1).astype(np.float64), head)
+        e = np.exp(logits - logits.max(1, keepdims=True))
+        ref.append((e / e.sum(1, keepdims=True))[:, 0])
+    ref = np.concatenate(ref)
+    err = np.abs(scores - ref).max()
+    print(f"config 5 (whisper-small + Q-adapter 512x512): scores {scores.round(4)} oracle {ref.round(4)} max err {err:.3e}")
+    assert err < 5e-3

@@ -24,14 +24,17 @@ def _signals(n, seed):
     return x
 
 
-@pytest.mark.parametrize("n,seed", [(1, 0), (5, 1), (9, 2)])
-def test_qscan_matches_restatement(T, gww, n, seed):
+@pytest.mark.parametrize("n,seed,shape", [(1, 0, (128, 128)), (5, 1, (128, 128)), (9, 2, (128, 128)),
+                                          (3, 3, (512, 512)), (2, 4, (80, 300))])
+def test_qscan_matches_restatement(T, gww, n, seed, shape):
+    """128 x 128 is the train.py adapter's resolution (MLGWSC-1/train.py:109), 512 x 512 the inference.py one
+    (inference.py:310: up-sampling in both axes for most rows), 80 x 300 an odd, non-square one."""
     from gw_whisper_amd.qscan import QScan
     x = _signals(n, seed)
-    ref, best = oq.qscan(x, return_plane=True)
-    qs = QScan(duration=1.0, sample_rate=2048, spectrogram_shape=[128, 128], qrange=[4, 128])
+    ref, best = oq.qscan(x, spectrogram_shape=shape, return_plane=True)
+    qs = QScan(duration=1.0, sample_rate=2048, spectrogram_shape=list(shape), qrange=[4, 128])
     out = qs(T.from_numpy(x.astype(np.float32)).cuda())
-    assert out.shape == (n, 128, 128)
+    assert out.shape == (n, *shape)
     assert int(qs.last_plane.item()) == best          # plane with the largest energy over the WHOLE batch
     got = out.cpu().numpy()
     scale = np.abs(ref).max()

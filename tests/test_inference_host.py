@@ -1,5 +1,7 @@
-"""Host-side logic of the search pipeline (gw_whisper_amd/inference.py) against restatements of the reference's
-MLGWSC-1/inference.py and train.py; runs on CPU."""
+"""Host-side logic of the search pipeline (gw_whisper_amd/inference.py): against ``golden/inference_host.npz``,
+produced by the reference's OWN ``SegmentSlicer`` / ``evaluate_slices`` / ``get_clusters`` (``tools/make_golden.py
+inference_host`` runs those definitions of ``MLGWSC-1/inference.py`` in the build container), and against
+restatements of the reference for randomised cases; runs on CPU."""
 import numpy as np
 import pytest
 import torch
@@ -80,6 +82,80 @@ def test_evaluate_slices_thresholds_like_the_reference_loop():
     ref = [[5.0 + i * 204 / 2048 + 0.6, float(scores[i])] for i in range(n) if scores[i] > 0.6]
     assert len(trig) == len(ref) > 0
     np.testing.assert_allclose(np.array(trig), np.array(ref), rtol=0, atol=1e-9)
+
+
+def test_slicer_time_stamps_are_bit_identical_to_the_reference_iterator(golden):
+    """>= 1e5 windows from a GPS-like start: the reference accumulates ``current_time += time_step_size``
+    (MLGWSC-1/inference.py:262-263); every time stamp must carry the same bits (sampled values + two checksums over
+    ALL windows), not merely agree to 1e-9."""
+    g = golden("inference_host.npz")
+    n = int(g["long_n_samples"])
+    sl = inf.DeviceSegmentSlicer(torch.zeros((2, n)), start_time=g["long_start"][()], delta_t=float(g["long_delta_t_attr"]),
+                                 device="cpu")
+    assert len(sl) == int(g["long_n_windows"]) >= 100000
+    ts = sl.times(0, len(sl)).numpy()
+    assert ts.dtype == np.float64
+    np.testing.assert_array_equal(ts[g["long_idx"]].view(np.uint64), g["long_times"].view(np.uint64))
+    assert np.bitwise_xor.reduce(ts.view(np.uint64)) == g["long_times_xor"]
+    assert np.add.reduce(ts.view(np.uint64)) == g["long_times_sum_u64"]
+    # a rank's shard sees the same stamps as the whole-segment run
+    a, b = inf.shard_windows(len(sl), 3, 8)
+    np.testing.assert_array_equal(sl.times(a, b).numpy().view(np.uint64), ts[a:b].view(np.uint64))
+    # at a power-of-two sample rate the step (204 / 2048 s) is dyadic and every partial sum is exact: there the
+    # closed form start + i * step is the same function
+    closed = float(g["long_start"]) + np.arange(len(sl)) * sl.time_step_size + 0.6
+    np.testing.assert_array_equal(closed, ts)
+    # ... at 4000 Hz it is not, and the running sum is what has to be reproduced
+    n = int(g["odd_n_samples"])
+    so = inf.DeviceSegmentSlicer(torch.zeros((2, n)), start_time=np.float64(1238166018.3),
+                                 delta_t=float(g["odd_delta_t_attr"]), device="cpu")
+    assert len(so) == int(g["odd_n_windows"]) and so.index_step_size == int(g["odd_index_step"])
+    to = so.times(0, len(so)).numpy()
+    np.testing.assert_array_equal(to[g["odd_idx"]].view(np.uint64), g["odd_times"].view(np.uint64))
+    assert np.bitwise_xor.reduce(to.view(np.uint64)) == g["odd_times_xor"]
+    closed = 1238166018.3 + np.arange(len(so)) * so.time_step_size + 0.6
+    assert (closed != to).any()
+
+
+def test_search_loop_equals_the_reference_loop_on_its_fixture(golden):
+    """Windows, scores, triggers ([time, score] pairs) and clusters of a 40 s two-detector segment: the reference's
+    TorchSegmentSlicer + DataLoader(256) + evaluate_slices + get_clusters against this build's strided views +
+    on-device threshold, same deterministic network, CPU fp32: everything bit-identical."""
+    from gw_whisper_amd import synth
+    from tests.helpers import search_toy_network
+    g = golden("inference_host.npz")
+    strain = synth.strain_segments(2, seed=77, n_samples=2048 * 40)
+    sl = inf.DeviceSegmentSlicer(strain, start_time=np.float64(1000.25), device="cpu")
+    assert len(sl) == int(g["short_n_windows"])
+    np.testing.assert_array_equal(sl.windows(7, 8)[0].numpy(), g["short_window_7"])
+    trig, vals = inf.evaluate_slices(sl, search_toy_network(), device="cpu", trigger_threshold=0.5)
+    np.testing.assert_array_equal(np.concatenate(vals), g["short_scores"])
+    assert [len(v) for v in vals] == [256, len(sl) - 256]
+    got = np.array(trig, np.float64).reshape(-1, 2)
+    assert len(got) == len(g["short_triggers"]) > 50
+    np.testing.assert_array_equal(got.view(np.uint64), g["short_triggers"].view(np.uint64))
+    t, v, tv = inf.get_clusters({"seg": trig})
+    np.testing.assert_array_equal(t, g["cl_short_times"])
+    np.testing.assert_array_equal(v, g["cl_short_vals"])
+    np.testing.assert_array_equal(tv, g["cl_short_tvars"])
+    # sharded evaluation (two ranks) concatenates to the same triggers
+    parts = []
+    for r in range(2):
+        parts += inf.evaluate_slices(sl, search_toy_network(), device="cpu", trigger_threshold=0.5,
+                                     window_range=inf.shard_windows(len(sl), r, 2))[0]
+    np.testing.assert_array_equal(np.array(parts).view(np.uint64), g["short_triggers"].view(np.uint64))
+
+
+def test_get_clusters_on_the_reference_fixture(golden):
+    """Gaps drawn around the 0.35 s threshold (0.35 and its float neighbour included), two keys + an empty one."""
+    g = golden("inference_host.npz")
+    t2, v2 = g["cl_in_times"], g["cl_in_vals"]
+    trig = {"a": [[float(a), float(b)] for a, b in zip(t2[:250], v2[:250])],
+            "b": [[float(a), float(b)] for a, b in zip(t2[250:], v2[250:])], "empty": []}
+    t, v, tv = inf.get_clusters(trig, cluster_threshold=0.35)
+    np.testing.assert_array_equal(t, g["cl_two_times"])
+    np.testing.assert_array_equal(v, g["cl_two_vals"])
+    np.testing.assert_array_equal(tv, g["cl_two_tvars"])
 
 
 def test_shard_windows_is_a_batch_aligned_partition():

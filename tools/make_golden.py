@@ -201,10 +201,148 @@ def make_adapter_schema():
     print("adapter_schema.json", len(schema["adapter_model.safetensors"]), "tensors;", list(schema["heads"]))
 
 
+def _reference_defs(rel_path, names, extra_ns=None):
+    """Execute selected top-level definitions of a reference file WITHOUT importing the module (its module-level
+    imports need h5py / pycbc / ml4gw / peft, absent here): the definitions are parsed out of the file where it lies
+    and compiled as they are.  Build-container only; nothing of the text is stored."""
+    import ast
+    import logging
+    from typing import Any, Dict, List, Optional, Tuple
+    path = os.path.join(REF, rel_path)
+    tree = ast.parse(open(path).read(), filename=path)
+    keep = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    assert sorted(n.name for n in keep) == sorted(names), [n.name for n in keep]
+    ns = {"np": np, "torch": torch, "nn": torch.nn, "logging": logging, "Any": Any, "Dict": Dict, "List": List,
+          "Optional": Optional, "Tuple": Tuple, "__name__": "reference_defs"}
+    ns.update(extra_ns or {})
+    mod = ast.Module(body=[ast.ImportFrom(module="__future__", names=[ast.alias(name="annotations")], level=0)] + keep,
+                     type_ignores=[])
+    code = compile(ast.fix_missing_locations(mod), path, "exec")
+    exec(code, ns)
+    return ns
+
+
+class _FakeDataset:
+    """Duck-typed stand-in for an h5py dataset (test INPUT, not reference code): ds[()] and ds.attrs."""
+    def __init__(self, data, attrs):
+        self._d, self.attrs, self.dtype = data, attrs, data.dtype
+    def __getitem__(self, k):
+        return self._d[k]
+
+
+def make_inference_host():
+    """Time stamps, windows, triggers and clusters from the reference's OWN SegmentSlicer / evaluate_slices /
+    get_clusters (MLGWSC-1/inference.py:140-166, 173-296, 454-489), run here on seeded strain."""
+    from torch.utils.data import DataLoader, IterableDataset
+    from tqdm import tqdm
+    ns = _reference_defs("MLGWSC-1/inference.py", ["get_clusters", "SegmentSlicer", "TorchSegmentSlicer", "evaluate_slices"],
+                         {"IterableDataset": IterableDataset, "DataLoader": DataLoader, "tqdm": tqdm, "h5py": None})
+    out = {}
+    # (a) a long segment: >= 1e5 windows, GPS-like start time, the stored delta_t attribute of the reference's files
+    dt_attr = 1.0 / 2048
+    start = np.float64(1238166018.0)
+    n_long = 204 * 120000 + 2048
+    long_data = np.zeros((2, n_long), np.float32)            # the time stamps do not depend on the samples
+    f = {det: {"k": _FakeDataset(long_data[i], {"delta_t": dt_attr, "start_time": start})} for i, det in enumerate(["H1", "L1"])}
+    sl = ns["SegmentSlicer"](f, "k", white=True)
+    n = len(sl)
+    it = iter(sl)
+    ts = np.empty(n, np.float64)
+    for i in range(n):
+        ts[i] = it.get_next_slice()[1]
+    idx = np.unique(np.concatenate([np.arange(0, 200), np.arange(0, n, 997), np.arange(n - 200, n)]))
+    out["long_n_samples"], out["long_n_windows"] = np.int64(n_long), np.int64(n)
+    out["long_start"], out["long_delta_t_attr"] = start, np.float64(dt_attr)
+    out["long_idx"], out["long_times"] = idx, ts[idx]
+    out["long_times_xor"] = np.bitwise_xor.reduce(ts.view(np.uint64))
+    out["long_times_sum_u64"] = np.add.reduce(ts.view(np.uint64))     # wraps: a second, order-free checksum
+    # (a') a sample rate that is not a power of two (4000 Hz): the running sum rounds at every step there
+    dt_odd = 1.0 / 4000.0
+    n_odd = 400 * 50000 + 2048
+    odd = np.zeros((2, n_odd), np.float32)
+    f = {det: {"k": _FakeDataset(odd[i], {"delta_t": dt_odd, "start_time": np.float64(1238166018.3)})} for i, det in enumerate(["H1", "L1"])}
+    sl = ns["SegmentSlicer"](f, "k", white=True)
+    it = iter(sl)
+    to = np.array([it.get_next_slice()[1] for _ in range(len(sl))], np.float64)
+    io = np.unique(np.concatenate([np.arange(0, 100), np.arange(0, len(sl), 499), np.arange(len(sl) - 100, len(sl))]))
+    out["odd_n_samples"], out["odd_n_windows"], out["odd_delta_t_attr"] = np.int64(n_odd), np.int64(len(sl)), np.float64(dt_odd)
+    out["odd_idx"], out["odd_times"] = io, to[io]
+    out["odd_times_xor"] = np.bitwise_xor.reduce(to.view(np.uint64))
+    out["odd_index_step"] = np.int64(sl.index_step_size)
+    # (b) a short segment through the reference's evaluate_slices with a deterministic network
+    strain = synth.strain_segments(2, seed=77, n_samples=2048 * 40)
+    f = {det: {"seg": _FakeDataset(strain[i], {"delta_t": dt_attr, "start_time": np.float64(1000.25)})}
+         for i, det in enumerate(["H1", "L1"])}
+    tsl = ns["TorchSegmentSlicer"](f, "seg", white=True)
+    from tests.helpers import search_toy_network
+    net = search_toy_network()
+    trig, vals = ns["evaluate_slices"](tsl, net, device="cpu", trigger_threshold=0.5)
+    out["short_n_windows"] = np.int64(len(tsl))
+    out["short_triggers"] = np.array(trig, np.float64).reshape(-1, 2)
+    out["short_scores"] = np.concatenate(vals).astype(np.float32)
+    out["short_window_7"] = tsl.dss[:, 7 * tsl.index_step_size: 7 * tsl.index_step_size + 2048].astype(np.float32)
+    # (c) get_clusters on the triggers above plus a synthetic two-key set with gaps around the 0.35 s threshold
+    rng = np.random.default_rng(5)
+    gaps = rng.choice([0.1, 0.2, 0.30000000000000004, 0.35, 0.35000000000000003, 0.4, 1.0], size=400)
+    t2 = 50.0 + np.add.accumulate(gaps)
+    v2 = rng.random(400)
+    trig2 = {"a": [[float(a), float(b)] for a, b in zip(t2[:250], v2[:250])],
+             "b": [[float(a), float(b)] for a, b in zip(t2[250:], v2[250:])], "empty": []}
+    out["cl_in_times"], out["cl_in_vals"] = t2, v2
+    for name, tr in (("short", {"seg": trig}), ("two", trig2)):
+        t, v, tv = ns["get_clusters"](tr, cluster_threshold=0.35)
+        out[f"cl_{name}_times"], out[f"cl_{name}_vals"], out[f"cl_{name}_tvars"] = t, v, tv
+    np.savez_compressed(os.path.join(GOLD, "inference_host.npz"), **out)
+    print("inference_host.npz", {k: np.shape(v) for k, v in out.items()}, "triggers", len(trig))
+
+
+def make_config4():
+    """BASELINE config 4: the reference's Glitch_classification/src/model.py (:4-39, imports only torch) on an HF
+    whisper-base encoder, num_classes = 22, 12 seeded segments through the log-mel front end the Glitch code uses
+    (Glitch_classification/src/dataset.py:46)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("glitch_model", os.path.join(REF, "Glitch_classification", "src", "model.py"))
+    gm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gm)
+    d, L, H, ffn = synth.ENCODER_SIZES["base"]
+    sd = synth.encoder_state_dict(d, L, H, ffn, seed=4)
+    enc = hf_encoder(d, L, H, ffn, sd)
+    model = gm.one_channel_ligo_binary_classifier(enc, num_classes=22).eval()      # eval(): Dropout is the identity
+    head = synth.head_state_dict([d, 512, 256, 128, 22], seed=769, sequential_stride=3)   # of 1000 seeds: 5 labels, largest margin
+    model.classifier.load_state_dict({k: torch.from_numpy(v) for k, v in head.items()})
+    fe = WhisperFeatureExtractor()
+    n = 12
+    seg = synth.strain_segments(n, seed=44)
+    t = np.arange(16000, dtype=np.float32) / 16000.0
+    for i in range(n):      # glitch-like bursts of different frequency / time / loudness (SNR ~ 1 ... 300: the loud ones
+        # move the log-mel clamp, i.e. the value of all 2900 padded frames) so that the classes differ
+        amp = 0.5 * (400.0 ** (i / (n - 1)))
+        seg[i] += (amp * np.sin(2 * np.pi * (30.0 + 35.0 * i) * t) * np.exp(-((t - 0.1 - 0.07 * i) / 0.03) ** 2)).astype(np.float32)
+    logits, last = [], []
+    with torch.no_grad():
+        for i in range(0, n, 4):
+            mel = fe([x for x in seg[i:i + 4]], sampling_rate=16000, return_tensors="pt").input_features
+            logits.append(model(mel).numpy())
+            last.append(enc(mel).last_hidden_state[:, -1, :].numpy())
+            print("config4 batch", i, flush=True)
+    logits = np.concatenate(logits).astype(np.float32)
+    # centre every class of the synthetic head (as make_config1 does) so that argmax gives mixed labels: the shift
+    # is added to the bias of the last Linear by the test
+    shift = (-np.mean(logits, axis=0)).astype(np.float32)
+    logits = logits + shift[None, :]
+    out = {"logits": logits, "labels": logits.argmax(1).astype(np.int64), "last_token": np.concatenate(last).astype(np.float32),
+           "class_bias_shift": shift}
+    srt = np.sort(logits, axis=1)
+    out["top2_margin"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "config4.npz"), **out)
+    print("config4.npz", {k: v.shape for k, v in out.items()}, "labels", out["labels"], "min margin", out["top2_margin"].min())
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["logmel", "encoder_small", "config1", "adapter_schema"]
+    which = sys.argv[1:] or ["logmel", "encoder_small", "config1", "adapter_schema", "inference_host", "config4"]
     for w in which:
         {"logmel": make_logmel, "encoder_small": make_encoder_small, "config1": make_config1,
-         "adapter_schema": make_adapter_schema}[w]()
+         "adapter_schema": make_adapter_schema, "inference_host": make_inference_host,
+         "config4": make_config4}[w]()
