@@ -36,7 +36,46 @@ import torch  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 HBM_PEAK_GBS = 8000.0
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # collected by tools/pmc_traffic.py (separate rocprofv3 --pmc passes)
 T_TOK, T_IN, DH = 1500, 3000, 64
+
+
+def launcher_command(argv, n_gpus, port, script=None):
+    """The N-rank launch of this script, as the driver itself would issue it (one rank per GPU over RCCL)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__), *argv]
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(argv, n_gpus, run=None):
+    """``python bench.py --gpus N`` without a torchrun environment: start N fresh rank processes as CHILDREN and
+    return their exit code.  Called before anything in this process touches the GPU (never exec / re-exec a process
+    that has initialised HIP: forbidden on the GPU boxes)."""
+    import subprocess
+    run = run or subprocess.run
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return run(launcher_command(argv, n_gpus, free_port()), env=env).returncode
+
+
+def csrc_hash():
+    """Hash of the kernel sources + ABI header: profiles/*pmc_traffic.json is stamped with it, and bench.py drops
+    `roofline.traffic` when the stamp no longer matches (a kernel change makes the pasted counters stale)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(root, "gw_whisper_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(root, "gw_whisper_amd", "csrc", "*.h")) + [os.path.join(root, "include", "gww.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def flops_per_segment(d, L, H, ffn, n_mels=80):
@@ -174,27 +213,33 @@ def dora_step(enc_name, per_gpu_batch, dev, world, steps=6, warmup=2):
             "loss": float(loss.detach())}
 
 
-def cpu_baseline(enc_name, n_seg=24):
-    """The numpy oracle (a CPU port of the HF arithmetic, not the reference itself) on a
-    bounded sample: n_seg segments of the same workload, all host cores via BLAS."""
+def cpu_baseline(enc_name, budget_s=20.0):
+    """The encoder forward on the host cores: the torch-CPU restatement of the HF arithmetic (oracle/encoder_torch.py, a
+    port pinned by the HF goldens, not the reference itself -- the reference tree does not travel to the GPU box), fp32,
+    all the threads torch uses here (stated), on a bounded sample of the same workload sized to ~budget_s seconds."""
+    import torch as T
     from gw_whisper_amd import synth
     from oracle import encoder as oenc
+    from oracle import encoder_torch as oet
     from oracle import logmel as olm
     sd = synth.named_encoder_state_dict(enc_name, seed=0)
     cfg = oenc.EncCfg.named(enc_name)
-    mel = olm.log_mel(synth.strain_segments(n_seg, seed=0))
-    oenc.encoder_forward(sd, mel[:1], cfg)                       # warm BLAS threads
+    threads = T.get_num_threads()
+    chunk = 4
+    mel = olm.log_mel(synth.strain_segments(chunk, seed=0))
+    oet.encoder_forward(sd, mel, cfg, chunk=chunk)                # warm the thread pool / oneDNN primitives
     t0 = time.perf_counter()
-    oenc.encoder_forward(sd, mel, cfg)
+    oet.encoder_forward(sd, mel, cfg, chunk=chunk)
+    probe = (time.perf_counter() - t0) / chunk
+    n_seg = int(min(256, max(chunk, round(budget_s / probe / chunk) * chunk)))
+    mel = olm.log_mel(synth.strain_segments(n_seg, seed=0))
+    t0 = time.perf_counter()
+    oet.encoder_forward(sd, mel, cfg, chunk=chunk)
     dt = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    return {"value": n_seg / dt, "unit": "segments/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n_seg} segments x [80,3000] log-mel, whisper-{enc_name} encoder fwd, numpy fp32 oracle, "
-                      f"{dt:.1f} s wall"}
+    return {"value": n_seg / dt, "unit": "segments/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n_seg} segments x [80,3000] log-mel, whisper-{enc_name} encoder fwd, torch-CPU fp32 restatement "
+                      f"(oracle/encoder_torch.py: oneDNN conv, threaded GEMMs, CPU SDPA), {threads} threads of "
+                      f"{os.cpu_count()} host CPUs, {dt:.1f} s wall"}
 
 
 def main():
@@ -213,16 +258,16 @@ def main():
     ap.add_argument("--no-pooled", action="store_true", help="skip the pooled (last-token-only) forward timing")
     ap.add_argument("--train-batch", type=int, default=32, help="per-GPU batch of the DoRA step (reference default 32)")
     ap.add_argument("--isolated", action="store_true", help="also time each kernel class in isolation")
+    ap.add_argument("--no-extra", action="store_true", help="skip the whisper-base forward / whisper-small DoRA step extras")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-        args.gpus = world
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher of N child ranks (nothing here has touched the GPU yet)
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -243,7 +288,24 @@ def main():
     # synthetic whitened-like 1 s strain -> HIP log-mel front end; features stay resident in HBM
     wave = torch.from_numpy(synth.strain_segments(B, seed=1000 + rank)).to(dev)
     mel = ops.logmel(wave)
-    fe_ms = time_kernel(lambda: ops.logmel(wave), iters=5, warm=1)
+    fe_call_ms = time_kernel(lambda: ops.logmel(wave), iters=10, warm=2)     # what a caller of ops.logmel pays (host incl.)
+    # ... and the device time of the same call (memset + k_logmel_frames_mfma + k_logmel_finalize) replayed from a
+    # hipGraph, so that the host-side cost of the Python call does not pace the GPU
+    fe_ms = None
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.logmel(wave)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fe_out = ops.logmel(wave)
+        fe_ms = time_kernel(graph.replay, iters=20, warm=2)
+        assert torch.equal(fe_out, mel)
+        del graph, fe_out
+    except Exception as exc:   # capture unavailable: report the call time only
+        print(f"[bench] front-end graph capture failed: {exc}", file=sys.stderr)
     # front end #2 (BASELINE configs 4 / 5): Q-scan of B two-detector 1 s windows at 2048 Hz -> [2 B, 128, 128]
     from gw_whisper_amd.qscan import QScan
     qs = QScan(duration=1.0, sample_rate=2048, spectrogram_shape=[128, 128], qrange=[4, 128])
@@ -307,6 +369,29 @@ def main():
         torch.cuda.empty_cache()
         train = dora_step(args.encoder, args.train_batch, dev, world)
 
+    # extras (never `value`): BASELINE configs 3 and 4 shapes in the same driver-run record -- whisper-small DoRA step
+    # (q, k, v targets, per-GPU batch 32 x 2 detectors, gradients all-reduced over RCCL when world > 1) and the
+    # whisper-base forward at B = 64
+    extra = None
+    if not args.no_extra and args.precision == "bf16" and args.encoder == "tiny":
+        torch.cuda.empty_cache()
+        extra = {}
+        db, Lb, Hb, fb = synth.ENCODER_SIZES["base"]
+        enc_b = WhisperEncoder.from_numpy_state_dict(synth.named_encoder_state_dict("base", seed=0),
+                                                     WhisperConfig.named("base"), precision="bf16").to(dev)
+        with torch.no_grad():
+            ms_b = time_kernel(lambda: enc_b.forward_raw(mel[:64], want_hidden=True, want_last=True), iters=5, warm=2)
+            ms_bp = time_kernel(lambda: enc_b.forward_raw(mel[:64], want_hidden=False, want_last=True), iters=5, warm=2)
+        tf_b = 64 * flops_per_segment(db, Lb, Hb, fb)["total"] / (ms_b * 1e-3) / 1e12
+        extra["whisper_base_forward"] = {"batch": 64, "ms_per_batch": ms_b, "segments_per_s_per_gpu": 64 / ms_b * 1e3,
+                                         "achieved_tflops_per_gpu": tf_b, "frac_of_bf16_mfma_peak": tf_b / MFMA_BF16_PEAK_TFLOPS,
+                                         "pooled_ms_per_batch": ms_bp, "workload": "BASELINE configs[3] encoder (22-class head is torch.nn)"}
+        del enc_b
+        torch.cuda.empty_cache()
+        extra["whisper_small_dora_step"] = dora_step("small", args.train_batch, dev, world, steps=4, warmup=2)
+        extra["whisper_small_dora_step"]["workload"] = "BASELINE configs[2]: whisper-small + DoRA fine-tune, data-parallel"
+        torch.cuda.empty_cache()
+
     if rank == 0:
         fl = flops_per_segment(d, L, H, ffn)
         fwd_tflops = B * fl["total"] / (ms_per_step * 1e-3) / 1e12
@@ -316,15 +401,20 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"whisper-{args.encoder} encoder fwd, batch {B} log-mel (80x3000) per GPU, "
-                                   f"1500 tokens, random-init weights (configs[1])",
+                                   f"1500 tokens, random-init weights"
+                                   + (" (BASELINE configs[1])" if (args.encoder, B) == ("tiny", 256) else ""),
                        "global_batch": B * world, "parallelism": f"dp{world}", "encoder": args.encoder,
                        "streams_per_gpu": 2 if args.split else 1},
             "forward": {"algorithmic_gflop_per_segment": fl["total"] / 1e9, "achieved_tflops_per_gpu": fwd_tflops,
                         "frac_of_bf16_mfma_peak": fwd_tflops / MFMA_BF16_PEAK_TFLOPS},
-            "frontend": {"kernel": "logmel (k_logmel_frames + k_logmel_finalize)", "ms_per_batch": fe_ms,
-                         "segments_per_s": B / fe_ms * 1e3,
-                         "algorithmic_gbs": B * (64000 + 960000) / fe_ms / 1e6,
-                         "frac_of_hbm_peak": B * (64000 + 960000) / fe_ms / 1e6 / HBM_PEAK_GBS},
+            "frontend": {"kernel": "logmel (memset + k_logmel_frames_mfma + k_logmel_finalize)",
+                         "ms_per_batch": fe_ms, "ms_per_call_incl_host": fe_call_ms,
+                         "what": "ms_per_batch = device time of one ops.logmel call replayed from a hipGraph; "
+                                 "ms_per_call_incl_host = the eager Python call (allocation of the 245 MB output, ctypes, "
+                                 "three enqueues), host-paced",
+                         "segments_per_s": B / (fe_ms or fe_call_ms) * 1e3,
+                         "algorithmic_gbs": B * (64000 + 960000) / (fe_ms or fe_call_ms) / 1e6,
+                         "frac_of_hbm_peak": B * (64000 + 960000) / (fe_ms or fe_call_ms) / 1e6 / HBM_PEAK_GBS},
             "frontend_qscan": {"kernel": "rDFT GEMM + k_qscan_tiles + k_qscan_interp (parity unpinned, DESIGN.md section 2)",
                                "ms_per_batch": q_ms, "windows_per_s": 2 * B / q_ms * 1e3,
                                "config": f"{2 * B} x 2048 samples, qrange [4, 128], 148 tiles rows, 128 x 128 output"},
@@ -334,6 +424,7 @@ def main():
             if pooled_ms else None,
             "dora_step_ms": train["ms"] if train else None,
             "dora_step": train,
+            "extra": extra,
         }
         if traced:
             M = B * T_TOK
@@ -348,11 +439,14 @@ def main():
                 "out_proj": (B * 2 * T_TOK * d * d, M * 2 * d * es),
                 "ln+fc1_gelu": (B * 2 * T_TOK * d * ffn, M * (d * 4 + ffn * es)),
                 "fc2": (B * 2 * T_TOK * d * ffn, M * (ffn + d) * es),
-                "final_layernorm": (0, M * d * 8),
+                # full final LayerNorm: x (+ the pending bf16 delta of the last fc2) in, fp32 out
+                "final_layernorm": (0, M * d * (8 + es)),
+                "layernorm_rows(B pooled rows)": (0, B * d * (8 + es)),
                 "mlp_fused(ln+fc1+gelu+fc2)": (B * 4 * T_TOK * d * ffn, M * d * (4 + 2 + 4 + 2)),
-                # + the next layer's LN1 + q/k/v: x, delta in; x_next (written twice: x_new, then in place) and qkv out
-                "mlp_fused+next_ln_qkv": (B * (4 * T_TOK * d * ffn + 2 * T_TOK * d * 3 * d),
-                                          M * d * (4 + 2 + 4 + 4 + 4) + M * 3 * d * 2),
+                # + the next layer's LN1 + q/k/v.  What the algorithm needs: x 4 B + delta 2 B in, x_next 4 B + qkv 6 B
+                # out = 16 B per element (a second write of the residual stream is NOT algorithmic: it shows up as
+                # pmc_hbm_bytes / algorithmic bytes > 1)
+                "mlp_fused+next_ln_qkv": (B * (4 * T_TOK * d * ffn + 2 * T_TOK * d * 3 * d), M * d * 16),
             }
             rows = []
             for name, (ms, cnt) in traced.items():
@@ -367,13 +461,19 @@ def main():
             # HBM traffic per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
             # separate runs; profiles/r01_pmc_traffic.json).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
             # for 16-B-per-lane reads on gfx950 (an upper bound where a kernel also issues 8-B-per-lane reads).
-            pmc = {}
+            pmc, pmc_note = {}, None
             try:
                 if args.encoder == "tiny" and B == 256 and args.precision == "bf16":
-                    pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                                      "r01_pmc_traffic.json")))["kernels"]
+                    prof = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                                       PMC_TRAFFIC_FILE)))
+                    if prof.get("csrc_hash") == csrc_hash():
+                        pmc = prof["kernels"]
+                    else:
+                        pmc_note = (f"profiles/{PMC_TRAFFIC_FILE} was collected for csrc hash {prof.get('csrc_hash')}, "
+                                    f"the kernels now hash to {csrc_hash()}: traffic dropped (stale)")
             except OSError:
                 pmc = {}
+            line["pmc_traffic_note"] = pmc_note
             for r in rows:
                 t = pmc.get(r["kernel"])
                 r["pmc_hbm_bytes"] = (t["fetch_bytes_corrected_x2"] + t["write_bytes"]) if t else None

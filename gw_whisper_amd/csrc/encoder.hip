@@ -74,7 +74,7 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 }  // namespace
 
 // kernel classes of one forward, for the optional per-kernel event trace (bench.py roofline)
-enum : int { TR_MEL = 0, TR_CONV1, TR_CONV2, TR_QKV, TR_ATTN, TR_OUT, TR_FC1, TR_FC2, TR_LN, TR_MLP, TR_MLPQKV, TR_COUNT };
+enum : int { TR_MEL = 0, TR_CONV1, TR_CONV2, TR_QKV, TR_ATTN, TR_OUT, TR_FC1, TR_FC2, TR_LN, TR_MLP, TR_MLPQKV, TR_LNROWS, TR_COUNT };
 
 struct TraceSpan { int cls; hipEvent_t a, b; };
 
@@ -231,7 +231,7 @@ extern "C" int gww_encoder_trace_classes(void) { return TR_COUNT; }
 extern "C" const char* gww_encoder_trace_class_name(int i) {
   static const char* names[TR_COUNT] = {"mel_to_tokens", "conv1_gelu", "conv2_gelu_pos", "ln+qkv_proj", "attention",
                                         "out_proj", "ln+fc1_gelu", "fc2", "final_layernorm", "mlp_fused(ln+fc1+gelu+fc2)",
-                                        "mlp_fused+next_ln_qkv"};
+                                        "mlp_fused+next_ln_qkv", "layernorm_rows(B pooled rows)"};
   return (i >= 0 && i < TR_COUNT) ? names[i] : "?";
 }
 
@@ -538,10 +538,10 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
                                  hipMemcpyDeviceToDevice, s));
         TR(TR_OUT, launch_gemm_bf16((const unsigned short*)ctx + (size_t)(T - 1) * d, (long)T * d, L.wo, L.bo, xl, nullptr,
                                     xm, B, d, d, EPI_RESID, 0, s, 0));
-        TR(TR_LN, launch_layernorm(xm, L.ln2w, L.ln2b, d1, 1, B, d, s));
+        TR(TR_LNROWS, launch_layernorm(xm, L.ln2w, L.ln2b, d1, 1, B, d, s));
         TR(TR_FC1, launch_gemm_bf16(d1, d, L.w1, L.b1, nullptr, nullptr, f1, B, F, d, EPI_GELU, 0, s, 0));
         TR(TR_FC2, launch_gemm_bf16(f1, F, L.w2, L.b2, xm, nullptr, xf, B, d, F, EPI_RESID, 0, s, 0));
-        TR(TR_LN, launch_layernorm_rows(xf, d, e->lnw, e->lnb, last_token, B, d, s, nullptr));
+        TR(TR_LNROWS, launch_layernorm_rows(xf, d, e->lnw, e->lnb, last_token, B, d, s, nullptr));
         return GWW_OK;
       }
       TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s, nullptr, false, q_log2));
@@ -584,10 +584,10 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
                                  hipMemcpyDeviceToDevice, s));
         TR(TR_OUT, launch_gemm_bf16((const unsigned short*)ctx + (size_t)(T - 1) * d, (long)T * d, L.wo, L.bo, xl, nullptr,
                                     xm, B, d, d, EPI_RESID, 0, s, 0));
-        TR(TR_LN, launch_layernorm(xm, L.ln2w, L.ln2b, h, 1, B, d, s));
+        TR(TR_LNROWS, launch_layernorm(xm, L.ln2w, L.ln2b, h, 1, B, d, s));
         TR(TR_FC1, launch_gemm_bf16(h, d, L.w1, L.b1, nullptr, nullptr, f1, B, F, d, EPI_GELU, 0, s, 0));
         TR(TR_FC2, launch_gemm_bf16(f1, F, L.w2, L.b2, xm, nullptr, xf, B, d, F, EPI_RESID, 0, s, 0));
-        TR(TR_LN, launch_layernorm_rows(xf, d, e->lnw, e->lnb, last_token, B, d, s, nullptr));
+        TR(TR_LNROWS, launch_layernorm_rows(xf, d, e->lnw, e->lnb, last_token, B, d, s, nullptr));
         return GWW_OK;
       }
       if (bf) TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s));
@@ -602,7 +602,7 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   // callers pool token T-1 (Signal_vs_Noise/src/model.py:25-26): that row alone is a fast output
   if (last_hidden) TR(TR_LN, launch_layernorm(xc, e->lnw, e->lnb, last_hidden, 0, M, d, s, pending));
   if (last_token)
-    TR(TR_LN, launch_layernorm_rows(xc + (long)(T - 1) * d, (long)T * d, e->lnw, e->lnb, last_token, B, d, s,
+    TR(TR_LNROWS, launch_layernorm_rows(xc + (long)(T - 1) * d, (long)T * d, e->lnw, e->lnb, last_token, B, d, s,
                                     pending ? (const char*)pending + (size_t)(T - 1) * d * 2 : nullptr));
 #undef TR
   return GWW_OK;

@@ -50,6 +50,35 @@ def shard_range(n_items: int, rank: int, world: int, batch: int = 1) -> Tuple[in
     return min(b0 * batch, n_items), min(b1 * batch, n_items)
 
 
+def epoch_steps(n_items: int, world: int, batch: int) -> int:
+    """Optimizer steps of one epoch -- THE SAME NUMBER ON EVERY RANK (each step is one collective): global step s
+    takes the ``world`` consecutive batches ``s * world ... s * world + world - 1``, one per rank; when the number of
+    batches is not a multiple of ``world`` the last step has fewer active ranks (``step_slice`` returns None for the
+    others, which contribute zeros; ``FlatGradBucket.all_reduce_mean`` then divides by the active count)."""
+    n_batches = (n_items + batch - 1) // batch
+    return (n_batches + world - 1) // world
+
+
+def step_slice(n_items: int, step: int, rank: int, world: int, batch: int):
+    """[lo, hi) of the items this rank trains on in global step ``step``, or None when it has no batch there."""
+    lo = (step * world + rank) * batch
+    return None if lo >= n_items else (lo, min(n_items, lo + batch))
+
+
+def step_active(n_items: int, step: int, world: int, batch: int) -> int:
+    """Ranks that hold a batch in global step ``step`` (known to every rank without communication)."""
+    return sum(step_slice(n_items, step, r, world, batch) is not None for r in range(world))
+
+
+def broadcast_scalar(value: float, world: int, device=None, src: int = 0) -> float:
+    """Rank ``src``'s value on every rank: early stopping / best-checkpoint decisions must not diverge."""
+    if world == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.broadcast(t, src=src)
+    return float(t.item())
+
+
 def gather_concat(local: torch.Tensor, n_items: int, rank: int, world: int, batch: int = 1) -> torch.Tensor | None:
     """Gather the per-rank result rows (in ``shard_range`` order) on rank 0."""
     if world == 1:
@@ -84,7 +113,8 @@ class FlatGradBucket:
     def zero(self):
         self.flat.zero_()
 
-    def all_reduce_mean(self, world: int):
+    def all_reduce_mean(self, world: int, active: int | None = None):
+        """Sum over ranks, divide by ``active`` (default ``world``): ranks without a batch in this step hold zeros."""
         if world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(world)
+            self.flat.div_(world if active is None else max(int(active), 1))

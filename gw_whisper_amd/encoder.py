@@ -263,17 +263,27 @@ class WhisperEncoder(nn.Module):
         return {lib().gww_encoder_trace_class_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
 
     def forward(self, input_features, attention_mask=None, **kwargs):
+        self._check_input(input_features)
         if self._wants_grad(input_features):
             # DoRA training step: HIP forward that keeps activations + HIP backward (training.py)
             from .training import encoder_train_forward
-            self._check_input(input_features)
             return BaseModelOutput(last_hidden_state=encoder_train_forward(self, input_features))
         hidden, _ = self.forward_raw(input_features, want_hidden=True, want_last=False)
         return BaseModelOutput(last_hidden_state=hidden)
 
     def _wants_grad(self, input_features) -> bool:
-        return torch.is_grad_enabled() and (self._has_trainable_adapters() or
-                                            (torch.is_tensor(input_features) and input_features.requires_grad))
+        if not torch.is_grad_enabled():
+            return False
+        # Only the frozen-base + DoRA backward exists (and the input gradient).  A trainable base parameter -- the
+        # reference's `full_finetune` method, Signal_vs_Noise/src/train.py:244-250, or an encoder used without peft
+        # whose parameters were never frozen -- or a plain-LoRA adapter would silently get no gradient: refuse.
+        base_trainable = [n for n, p in self.named_parameters() if p.requires_grad and "lora_" not in n]
+        if base_trainable:
+            raise _lib.GwwError(
+                "WhisperEncoder: autograd is on and base parameters require grad (e.g. " + base_trainable[0] + "): only "
+                "the frozen-base + DoRA training step (and the input gradient) is implemented -- freeze the encoder "
+                "(get_peft_model does) or run under torch.no_grad()")
+        return self._has_trainable_adapters() or (torch.is_tensor(input_features) and input_features.requires_grad)
 
     def _has_trainable_adapters(self) -> bool:
         for layer in self.layers:
@@ -297,8 +307,8 @@ class WhisperEncoder(nn.Module):
         """``self(mel).last_hidden_state[:, -1, :]`` without materialising the other
         1499 rows of the final LayerNorm (reference ``src/model.py:25-26``).  Differentiable: with trainable
         adapters (or an input that requires grad) this is the pooled training step of ``training.py``."""
+        self._check_input(input_features)
         if self._wants_grad(input_features):
             from .training import encoder_train_forward
-            self._check_input(input_features)
             return encoder_train_forward(self, input_features, pooled=True)
         return self.forward_raw(input_features, want_hidden=False, want_last=True)[1]

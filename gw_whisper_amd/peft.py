@@ -220,6 +220,8 @@ class PeftModel(nn.Module):
         known = {f for f in LoraConfig.__dataclass_fields__}
         cfg = LoraConfig(**{k: v for k, v in raw.items() if k in known and k != "inference_mode"})
         cfg.inference_mode = not is_trainable
+        for p in model.parameters():     # peft freezes the base model when it injects the adapter
+            p.requires_grad = False
         peft = cls(model, cfg)
         sd = load_file(os.path.join(model_id, "adapter_model.safetensors"))
         remap = {}

@@ -111,16 +111,21 @@ def main(args):
     matched = [m for p in patterns for m in fnmatch.filter(module_names, p)]
     if args.method != "DoRA":
         raise NotImplementedError("only --method DoRA has a HIP backward (LoRA / full_finetune are not built)")
-    peft = get_peft_model(encoder, LoraConfig(use_dora=True, r=args.lora_rank, lora_alpha=args.lora_alpha,
-                                              target_modules=matched)).to(device)
+    if args.load_model_path:
+        # resume (src/train.py:44-60): the saved adapter is loaded onto the BARE encoder -- PeftModel.from_pretrained
+        # wraps the nn.Linear targets itself -- and stays trainable
+        from gw_whisper_amd.peft import PeftModel
+        peft = PeftModel.from_pretrained(encoder, os.path.join(args.load_model_path, args.load_lora_weights),
+                                         is_trainable=True).to(device)
+    else:
+        peft = get_peft_model(encoder, LoraConfig(use_dora=True, r=args.lora_rank, lora_alpha=args.lora_alpha,
+                                                  target_modules=matched)).to(device)
     for name, p in peft.named_parameters():
         p.requires_grad = "lora" in name
     model = two_channel_ligo_binary_classifier(peft).to(device)
     if args.load_model_path:
-        from gw_whisper_amd.peft import PeftModel
-        base = peft.base_model.model
-        model.encoder = PeftModel.from_pretrained(base, args.load_model_path + args.load_lora_weights, is_trainable=True)
-        model.classifier.load_state_dict(torch.load(args.load_model_path + args.load_dense_weights, map_location=device))
+        model.classifier.load_state_dict(torch.load(os.path.join(args.load_model_path, args.load_dense_weights),
+                                                    map_location=device))
     params = [p for p in model.parameters() if p.requires_grad]
     optimizer = torch.optim.AdamW(params, lr=args.learning_rate, betas=(0.9, 0.999), eps=1e-08)
     bucket = gdist.FlatGradBucket(params)
@@ -164,23 +169,28 @@ def main(args):
     for epoch in range(args.num_epochs):
         model.train()
         order = np.random.default_rng(args.seed + 1 + epoch).permutation(train_idx)
-        lo, hi = gdist.shard_range(len(order), rank, world, args.batch_size)
-        t0, run, nb = time.time(), 0.0, 0
-        for i in range(lo, hi, args.batch_size):
-            idx = order[i:min(hi, i + args.batch_size)]
-            a, b = features(idx)
-            y = torch.from_numpy(labels[idx]).view(-1, 1).to(device)
+        t0, run, nb, seen = time.time(), 0.0, 0, 0
+        # every rank runs the SAME number of steps (one all-reduce each); a rank without a batch in the last step
+        # contributes zeros and the mean is taken over the active ranks
+        for step in range(gdist.epoch_steps(len(order), world, args.batch_size)):
+            sl = gdist.step_slice(len(order), step, rank, world, args.batch_size)
             bucket.zero()
-            loss = criterion(model(a, b), y)
-            loss.backward()
-            bucket.all_reduce_mean(world)
+            if sl is not None:
+                idx = order[sl[0]:sl[1]]
+                a, b = features(idx)
+                y = torch.from_numpy(labels[idx]).view(-1, 1).to(device)
+                loss = criterion(model(a, b), y)
+                loss.backward()
+                run += loss.item()
+                nb += 1
+                seen += len(idx)
+            bucket.all_reduce_mean(world, active=gdist.step_active(len(order), step, world, args.batch_size))
             optimizer.step()
-            run += loss.item()
-            nb += 1
         train_loss = run / max(nb, 1)
         val_loss, val_auc = evaluate()
+        val_loss = gdist.broadcast_scalar(val_loss, world, device)     # one decision for all ranks
         rec = {"epoch": epoch + 1, "train_loss": train_loss, "val_loss": val_loss, "val_auc": val_auc,
-               "epoch_s": time.time() - t0, "segments_per_s": world * (hi - lo) / max(time.time() - t0, 1e-9)}
+               "epoch_s": time.time() - t0, "segments_per_s": len(order) / max(time.time() - t0, 1e-9), "rank0_segments": seen}
         if rank == 0:
             print(f"Epoch {epoch + 1}/{args.num_epochs}, Train Loss: {train_loss:.4f}, Val Loss: {val_loss:.4f}, "
                   f"Val AUC: {val_auc:.4f}")

@@ -66,3 +66,74 @@ def test_two_rank_gloo(tmp_path):
     g0 = torch.load(tmp_path / "g0.pt")
     g1 = torch.load(tmp_path / "g1.pt")
     torch.testing.assert_close(g0, g1)          # replicated parameters see identical gradients
+
+
+def test_epoch_plan_gives_every_rank_the_same_number_of_steps():
+    for n, world, batch in [(77, 2, 16), (77, 3, 16), (5, 8, 1), (64, 2, 32), (1, 4, 32), (0, 2, 8)]:
+        steps = gdist.epoch_steps(n, world, batch)
+        seen = []
+        for s in range(steps):
+            act = 0
+            for r in range(world):
+                sl = gdist.step_slice(n, s, r, world, batch)
+                if sl is not None:
+                    seen += list(range(*sl))
+                    act += 1
+            assert act == gdist.step_active(n, s, world, batch) >= 1
+        assert seen == list(range(n))                 # every item exactly once, in order
+        assert gdist.step_slice(n, steps, 0, world, batch) is None
+
+
+def _epoch_worker(rank, world, port, tmp):
+    """The harness's epoch loop (harness/run_train.py) with a toy model: 77 items at batch 16 = 5 batches on 2 ranks --
+    3 steps on EVERY rank, the last one with a single active rank."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    gdist.init("gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Linear(6, 1)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    bucket = gdist.FlatGradBucket(model.parameters())
+    g = torch.Generator().manual_seed(1)
+    X, y = torch.randn(77, 6, generator=g), torch.randn(77, 1, generator=g)
+    n_collectives = 0
+    for epoch in range(2):
+        for step in range(gdist.epoch_steps(77, world, 16)):
+            sl = gdist.step_slice(77, step, rank, world, 16)
+            bucket.zero()
+            if sl is not None:
+                torch.nn.functional.mse_loss(model(X[sl[0]:sl[1]]), y[sl[0]:sl[1]]).backward()
+            bucket.all_reduce_mean(world, active=gdist.step_active(77, step, world, 16))
+            n_collectives += 1
+            opt.step()
+        val = gdist.broadcast_scalar(float(rank) + 0.25, world)        # decisions come from rank 0 on every rank
+        assert val == 0.25
+    torch.save({"w": model.weight.detach().clone(), "b": model.bias.detach().clone(), "n": n_collectives},
+               os.path.join(tmp, f"e{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_epoch_loop_with_a_ragged_number_of_batches(tmp_path):
+    port = _free_port()
+    mp.spawn(_epoch_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    e0, e1 = torch.load(tmp_path / "e0.pt"), torch.load(tmp_path / "e1.pt")
+    assert e0["n"] == e1["n"] == 2 * 3
+    assert torch.equal(e0["w"], e1["w"]) and torch.equal(e0["b"], e1["b"])      # replicas stay in lock step
+    # single process, same schedule by hand: mean over the active batches of every global step
+    torch.manual_seed(0)
+    model = torch.nn.Linear(6, 1)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(1)
+    X, y = torch.randn(77, 6, generator=g), torch.randn(77, 1, generator=g)
+    for epoch in range(2):
+        for step in range(3):
+            opt.zero_grad()
+            sls = [gdist.step_slice(77, step, r, 2, 16) for r in range(2)]
+            sls = [s for s in sls if s is not None]
+            for lo, hi in sls:
+                (torch.nn.functional.mse_loss(model(X[lo:hi]), y[lo:hi]) / len(sls)).backward()
+            opt.step()
+    torch.testing.assert_close(e0["w"], model.weight.detach())
+    torch.testing.assert_close(e0["b"], model.bias.detach())

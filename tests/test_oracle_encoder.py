@@ -173,3 +173,14 @@ def test_adapter_schema_fixture():
     cfg = sc["adapter_config.json"]
     assert cfg["use_dora"] is True and cfg["r"] == 8 and cfg["lora_alpha"] == 32
     assert cfg["peft_type"] == "LORA"
+
+
+def test_torch_cpu_restatement_matches_hf_golden(golden):
+    """oracle/encoder_torch.py (bench.py's cpu_baseline leg) is pinned by the same HF golden as the numpy oracle."""
+    from oracle import encoder_torch
+    g = golden("encoder_small.npz")
+    sd = synth.encoder_state_dict(128, 2, 2, 512, seed=3)
+    mel = logmel.log_mel(synth.strain_segments(2, seed=21))
+    out = encoder_torch.encoder_forward(sd, mel, encoder.EncCfg(128, 2, 2, 512), chunk=1)
+    np.testing.assert_allclose(out[:, g["rows"]], g["final"], atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(np.abs(out).mean(axis=(1, 2)), g["final_mean_abs"], rtol=1e-4)

@@ -93,3 +93,70 @@ def test_unknown_target_raises():
     enc = WhisperEncoder(WhisperConfig(128, 1, 2, 512))
     with pytest.raises(ValueError, match="not found"):
         get_peft_model(enc, LoraConfig(use_dora=True, target_modules=["layers.0.self_attn.o_proj"]))
+
+
+REF_ADAPTER = "/root/reference/Signal_vs_Noise/results/Two_detectors/models/best_lora_weights"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_ADAPTER), reason="reference tree absent (GPU box): build-container pin only")
+def test_the_adapter_the_reference_ships_loads_and_round_trips(tmp_path):
+    """The REAL ``adapter_model.safetensors`` / ``adapter_config.json`` the authors publish (trained with peft 0.12.0),
+    through ``PeftModel.from_pretrained`` exactly as ``Signal_vs_Noise/src/train.py:50`` does: every tensor lands in the
+    module peft's key names, ``save_pretrained`` writes back a file with the same keys, shapes, dtypes AND bytes, and
+    the config round-trips field by field."""
+    from safetensors import safe_open
+    enc = WhisperEncoder(WhisperConfig.named("tiny"))
+    peft = PeftModel.from_pretrained(enc, REF_ADAPTER)
+    with safe_open(os.path.join(REF_ADAPTER, "adapter_model.safetensors"), "pt") as f:
+        shipped = {k: f.get_tensor(k) for k in f.keys()}
+    assert len(shipped) == 24
+    sd = peft.state_dict()
+    for k, v in shipped.items():
+        rk = (k + ".default.weight") if k.endswith("lora_magnitude_vector") else \
+            k.replace(".lora_A.weight", ".lora_A.default.weight").replace(".lora_B.weight", ".lora_B.default.weight")
+        assert rk in sd, rk
+        assert torch.equal(sd[rk], v)
+    # only k_proj / v_proj of the 4 layers are wrapped; q_proj / out_proj stay plain Linear; nothing trainable
+    wrapped = [n for n, m in peft.named_modules() if hasattr(m, "lora_A")]
+    assert len(wrapped) == 8 and all(n.endswith(("k_proj", "v_proj")) for n in wrapped)
+    assert not any(p.requires_grad for p in peft.parameters())
+    # the trained adapters are not the identity: B != 0 and m moved away from its init
+    lin = peft.base_model.model.layers[0].self_attn.v_proj
+    assert torch.count_nonzero(lin.lora_B["default"].weight) > 0
+    peft.save_pretrained(str(tmp_path))
+    with safe_open(str(tmp_path / "adapter_model.safetensors"), "pt") as f:
+        again = {k: f.get_tensor(k) for k in f.keys()}
+    assert again.keys() == shipped.keys()
+    for k in shipped:
+        assert again[k].dtype == shipped[k].dtype and torch.equal(again[k], shipped[k]), k
+    ref_cfg = json.load(open(os.path.join(REF_ADAPTER, "adapter_config.json")))
+    cfg = json.load(open(tmp_path / "adapter_config.json"))
+    assert set(cfg) == set(ref_cfg)
+    for k in ref_cfg:
+        assert (sorted(cfg[k]) == sorted(ref_cfg[k])) if k == "target_modules" else (cfg[k] == ref_cfg[k]), k
+
+
+def test_datasets_directory_round_trip_through_the_harness_loader(tmp_path):
+    """The reference's training data are HF ``datasets`` directories with the columns h1_timeseries / l1_timeseries /
+    labels / injection_snr (Signal_vs_Noise/src/dataset.py:18, utils/preprocess.py:111-132), optionally split into
+    ``chunk*`` sub-directories (run_train.py:73-82): ``harness/run_train.py::load_arrays`` reads both layouts."""
+    import importlib.util
+    import types
+    import numpy as np
+    from datasets import Dataset
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_train_h", os.path.join(root, "harness", "run_train.py"))
+    rt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rt)
+    rng = np.random.default_rng(0)
+    cols = {"h1_timeseries": rng.standard_normal((10, 16000)).astype(np.float32),
+            "l1_timeseries": rng.standard_normal((10, 16000)).astype(np.float32),
+            "labels": (np.arange(10) % 2).astype(np.float32), "injection_snr": rng.uniform(5, 20, 10).astype(np.float32)}
+    as_rows = {k: [r.tolist() for r in v] if v.ndim == 2 else v.tolist() for k, v in cols.items()}   # Arrow float lists
+    Dataset.from_dict(as_rows).save_to_disk(str(tmp_path / "whole"))
+    for lo, hi, name in ((0, 6, "chunk0"), (6, 10, "chunk1")):
+        Dataset.from_dict({k: v[lo:hi] for k, v in as_rows.items()}).save_to_disk(str(tmp_path / "chunked" / name))
+    for path in ("whole", "chunked"):
+        got = rt.load_arrays(types.SimpleNamespace(synthetic=0, data_path=str(tmp_path / path)))
+        for g, k in zip(got, ("h1_timeseries", "l1_timeseries", "labels", "injection_snr")):
+            assert g.dtype == np.float32 and np.array_equal(g, cols[k]), (path, k)
