@@ -271,6 +271,260 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? GWW_ATT_MINBLK : 1) void k_atten
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The kernel the inference path launches (q in log2 units).  Same dataflow and occupancy as k_attention_bf16 above
+// (one tile = S, softmax, P V back to back; three waves per SIMD supply the overlap), with the instruction stream
+// of a 64-key tile cut from ~225 to ~170 -- the kernel is bound by instruction issue, not by memory or LDS
+// (DESIGN.md section 4):
+//   * scores arrive in log2 units (log2(e) / 8 is folded into the packed q panel: one rounding of the fp32
+//     product instead of a multiply per score) and the running reference -m enters THROUGH THE MATRIX PIPE: the
+//     accumulator chain of each 32-key half starts with one extra MFMA  ones[key][k] x mref[k][q], where mref
+//     holds -m of the lane's query as a bf16 hi + lo pair in k = 0, 1 (16 significant bits; whatever the pair
+//     sums to IS the reference -- any reference is exact algebra as long as numerator and denominator share it).
+//     p = v_exp_f32(s) then needs no subtract / multiply-add per score (31 VALU instructions per tile) and no
+//     persistent 16-register C operand (what cost the pipelined kernel below its third wave);
+//   * the reference moves only when some row's tile maximum exceeds it by more than 2^kDeferL2 (deferred rescale,
+//     rare path: O, l and the tile's scores are re-based there); the FIRST tile is scored against 0 and then always
+//     re-based to its own row maximum, so there is no -inf reference and no underflow for uniformly negative rows;
+//   * K / V tile addresses are a scalar tile base + a per-lane 32-bit offset that never changes (a second offset
+//     set clamps the rows of the ragged last tile), and every LDS address is a per-lane base + an immediate: the
+//     tile loop is unrolled by two so the buffer parity is a compile-time constant.
+// VAR (tuning aid, GWW_ATT_VAR): bit 0 = K / V global loads issued after the exponentials instead of at the top of the
+// tile; bit 1 = softmax denominator by 32 v_add_f32 per tile instead of the ones-MFMA (frees its 16 accumulators)
+template <int NW, int VAR>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void k_attention_l2_bf16(const unsigned short* __restrict__ qkv,
+                                                                              unsigned short* __restrict__ ctx,
+                                                                              float* __restrict__ lse, int T, int H,
+                                                                              int q_tiles, int qt0) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KB * DH * 2];   // K0 | K1 | V0 | V1, 8 KB each
+  constexpr int TILE_BYTES = KB * DH * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned nblk = gridDim.x, per = nblk >> 3;
+  const unsigned wid = blockIdx.x < 8 * per ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;   // XCD-aware order
+  const int qt = qt0 + wid % q_tiles;
+  const int bh = wid / q_tiles;
+  const int b = bh / H, h = bh - b * H;
+  const int d = H * DH;
+  const long row_stride = 3L * d;
+  const unsigned short* base = qkv + (long)b * T * row_stride;
+  const unsigned short* qp = base + h * DH;
+  const unsigned short* kp = base + d + h * DH;
+  const unsigned short* vp = base + 2 * d + h * DH;
+  const int r = lane & 31, hh = lane >> 5;
+  const int q_row = qt * (NW * 32) + wave * 32 + r;
+  const int q_ld = q_row < T ? q_row : T - 1;
+  bf16x8 qf[4];   // B operand of K Q^T: Q[q = r][dh = 16 s + 8 hh + j], log2 units
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + (long)q_ld * row_stride + 16 * s + 8 * hh);
+
+  // ---- staging: 512 16-byte chunks of K and of V per tile, NCH per thread
+  constexpr int NCH = 512 / (NW * 64);
+  const int n_kt = (T + KB - 1) / KB;
+  unsigned off_full[NCH];   // BYTE offset of the thread's chunk from the tile base: base (scalar) + zext(offset) addressing
+  int lk_off[NCH], lv_off[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + NW * 64 * i, row = c >> 3, chunk = c & 7;
+    off_full[i] = (unsigned)(row * (int)row_stride * 2 + chunk * 16);
+    lk_off[i] = k_off(row, chunk);
+    lv_off[i] = 2 * TILE_BYTES + v_off(row, chunk * 16);
+  }
+  u32x4 rk[NCH], rv[NCH];
+  auto gload = [&](int kt) {
+    const char* kb = reinterpret_cast<const char*>(kp + (long)kt * KB * row_stride);   // wave-uniform: scalar registers
+    const char* vb = reinterpret_cast<const char*>(vp + (long)kt * KB * row_stride);
+    if (kt != n_kt - 1 || (T % KB) == 0) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        rk[i] = *reinterpret_cast<const u32x4*>(kb + off_full[i]);
+        rv[i] = *reinterpret_cast<const u32x4*>(vb + off_full[i]);
+      }
+    } else {   // ragged last tile (once per workgroup): rows past T - 1 are clamped to it (never read past the tensor)
+      const int last_row = T - 1 - kt * KB;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = tid + NW * 64 * i;
+        int row = c >> 3;
+        row = row < last_row ? row : last_row;
+        const unsigned o = (unsigned)(row * (int)row_stride * 2 + (c & 7) * 16);
+        rk[i] = *reinterpret_cast<const u32x4*>(kb + o);
+        rv[i] = *reinterpret_cast<const u32x4*>(vb + o);
+      }
+    }
+  };
+  auto lstore = [&](auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      *reinterpret_cast<u32x4*>(lds + BUF * TILE_BYTES + lk_off[i]) = rk[i];
+      *reinterpret_cast<u32x4*>(lds + BUF * TILE_BYTES + lv_off[i]) = rv[i];
+    }
+  };
+
+  // ---- per-lane LDS bases of the fragment reads (everything else is an immediate)
+  // K: row 32 g + r, chunk (2 s + hh) ^ ((r >> 1) & 7)        V^T: row 32 g + 16 s + 4 hh + tr_q (+ 8), column bytes
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+  const int tr_colbyte = (((lane & 31) >> 4) * 16 + 4 * tr_p) * 2;
+  const unsigned char* kbase[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) kbase[s] = lds + k_off(r, 2 * s + hh);
+  const unsigned char* vbase[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) vbase[n] = lds + 2 * TILE_BYTES + v_off(4 * hh + tr_q, 64 * n + tr_colbyte);
+
+  f32x16 ot[2], lt;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { ot[0][j] = 0.f; ot[1][j] = 0.f; lt[j] = 0.f; }
+  bf16x8 ones, mref;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ones[j] = (__bf16)1.0f; mref[j] = (__bf16)0.0f; }
+  float l_run = 0.f;   // VAR bit 1: this lane's half of the denominator
+  float m_run = 0.f;   // the reference the scores are taken against, log2 units (== -(hi + lo) of mref)
+  constexpr float kDeferL2 = 8.0f * kLog2e;
+
+  typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+  auto tile = [&](int kt, auto buf_c, auto first_c, auto masked_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+    constexpr bool FIRST = decltype(first_c)::value, MASKED = decltype(masked_c)::value;
+    constexpr bool LATE = (VAR & 1) != 0, VSUM = (VAR & 2) != 0;
+    if constexpr (!LATE) { if (kt + 1 < n_kt) gload(kt + 1); }
+    // ---- S^T - m = [ones | K] [mref | Q]^T : st[g][reg] <-> key 32 g + (reg & 3) + 8 (reg >> 2) + 4 hh, q = r
+    f32x16 st[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f32x16 z;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) z[j] = 0.f;
+      if constexpr (FIRST) st[g] = z;
+      else st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, mref, z, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase[s] + BUF * TILE_BYTES + g * (32 * 128));
+        st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[g], 0, 0, 0);
+      }
+    }
+    if constexpr (MASKED) {   // keys >= T of the ragged last tile
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int key = kt * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
+          if (key >= T) st[g][j] = -INFINITY;
+        }
+    }
+    float tmax = st[0][0];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tmax = fmaxf(tmax, st[g][j]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    if (FIRST || __builtin_amdgcn_ballot_w64(tmax > kDeferL2) != 0) {   // wave-uniform, rare after the first tile
+      // move the reference of every row that needs it: the new one is what the bf16 pair can represent
+      const float want = m_run + (FIRST ? tmax : fmaxf(tmax, 0.f));
+      const __bf16 hi = (__bf16)(-want);
+      const __bf16 lo = (__bf16)(-want - (float)hi);
+      const float m_new = -((float)hi + (float)lo);
+      const float dm = m_new - m_run;
+      const float alpha = __builtin_amdgcn_exp2f(-dm);
+      m_run = m_new;
+      if constexpr (VSUM && !FIRST) l_run *= alpha;
+      mref[0] = hh == 0 ? hi : (__bf16)0.0f;
+      mref[1] = hh == 0 ? lo : (__bf16)0.0f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if constexpr (!FIRST) {   // first tile: O = l = 0, and 2^-dm may overflow for uniformly negative rows
+          if constexpr (!VSUM) lt[j] *= alpha;
+          ot[0][j] *= alpha;
+          ot[1][j] *= alpha;
+        }
+        st[0][j] -= dm;
+        st[1][j] -= dm;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) st[g][j] = __builtin_amdgcn_exp2f(st[g][j]);
+    // the next tile's K / V leave for the registers here (issue late, write after the P V product: the staging
+    // registers are not live across the score phase, whose 8 K fragments need the room)
+    if constexpr (LATE) { if (kt + 1 < n_kt) gload(kt + 1); }
+    if constexpr (VSUM) {
+      float ps = 0.f;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ps += st[g][j];
+      l_run += ps;
+    }
+    // ---- O^T += V^T P^T, l += 1^T P^T : B operand = bf16(st) registers 8 s .. 8 s + 7 of k-step s
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = cvt8(st[g], 8 * s);
+        if constexpr (!VSUM) lt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lt, 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const unsigned char* vb = vbase[n] + BUF * TILE_BYTES + (32 * g + 16 * s) * 128;
+          const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)vb);
+          const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vb + 8 * 128));
+          bf16x8 vf;
+          vf[0] = lo4[0]; vf[1] = lo4[1]; vf[2] = lo4[2]; vf[3] = lo4[3];
+          vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
+          ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[n], 0, 0, 0);
+        }
+      }
+    }
+    if (kt + 1 < n_kt) lstore(std::integral_constant<int, BUF ^ 1>{});
+    __syncthreads();
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using Yes = std::true_type;
+  using No = std::false_type;
+
+  gload(0);
+  lstore(P0{});
+  __syncthreads();
+  const bool ragged = (T % KB) != 0;
+  if (n_kt == 1) {
+    if (ragged) tile(0, P0{}, Yes{}, Yes{});
+    else tile(0, P0{}, Yes{}, No{});
+  } else {
+    tile(0, P0{}, Yes{}, No{});
+    int kt = 1;
+    for (; kt + 2 <= n_kt - 1; kt += 2) {
+      tile(kt, P1{}, No{}, No{});
+      tile(kt + 1, P0{}, No{}, No{});
+    }
+    if (kt == n_kt - 2) {   // two tiles left (kt odd)
+      tile(kt, P1{}, No{}, No{});
+      if (ragged) tile(kt + 1, P0{}, No{}, Yes{});
+      else tile(kt + 1, P0{}, No{}, No{});
+    } else {                // one tile left
+      if (ragged) tile(kt, P1{}, No{}, Yes{});
+      else tile(kt, P1{}, No{}, No{});
+    }
+  }
+
+  const float l_tot = (VAR & 2) ? l_run + __shfl_xor(l_run, 32, 64) : lt[0];
+  const float inv = 1.0f / l_tot;
+  if (lse && q_row < T && hh == 0)
+    lse[((long)b * H + h) * T + q_row] = (m_run + __log2f(l_tot)) * 0.69314718055994530942f;   // natural log
+  if (q_row < T) {
+    unsigned short* orow = ctx + ((long)b * T + q_row) * d + h * DH;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int dh = 32 * n + 8 * c + 4 * hh;
+        u32x2 o = {pack2bf(ot[n][4 * c] * inv, ot[n][4 * c + 1] * inv),
+                   pack2bf(ot[n][4 * c + 2] * inv, ot[n][4 * c + 3] * inv)};
+        *reinterpret_cast<u32x2*>(orow + dh) = o;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Software-pipelined form of the same kernel (experimental: GWW_ATT_PIPE=1 makes the encoder use it).
 // The kernel above runs S = K Q^T, the softmax VALU and the P V product of ONE tile back to back, so inside a wave
 // the matrix pipe idles through the 32 v_exp / 16 cvt / 20 max of every tile and the VALU idles through the MFMAs
@@ -620,13 +874,16 @@ __global__ __launch_bounds__(NW * 64, MB == 1 ? 2 : 1) void k_attention_pipe_bf1
 
 // last_tile_only: compute only the query tile that holds token T - 1 (the other rows of ctx are left untouched) --
 // the pooled forward needs nothing else of the last layer's attention.
-// q_log2: q was projected with log2(e) / 8 instead of 1 / 8 -> the software-pipelined kernel.
-// attention_pipe_enabled(): whether the encoder's fast path packs its q panel that way and launches that kernel.
-// OFF by default: measured 1.21-1.25 ms per whisper-tiny layer at B = 256 against 1.12-1.14 ms for the kernel above
-// (GWW_ATT_PIPE=1 to compare) -- at two waves per SIMD (256 registers) the better intra-wave overlap does not pay
-// for the third wave the plain kernel keeps; with its K / V loads removed it still needs 1.00 ms, i.e. both
-// kernels are bound by instruction issue per wave (~235 instructions per 64-key tile), not by the memory system.
-bool attention_pipe_enabled() {
+// q_log2: q was projected with log2(e) / 8 instead of 1 / 8 -> k_attention_l2_bf16 (reference through the matrix pipe).
+// attention_log2q_enabled(): whether the encoder's inference path packs its q panels that way (default; GWW_ATT_LOG2Q=0
+// falls back to natural-unit q and k_attention_bf16, the kernel the training forward uses).
+// GWW_ATT_PIPE=1: launch the experimental software-pipelined kernel for log2-unit q instead (measured slower: 1.20 ms
+// against 1.13 ms for k_attention_bf16 per whisper-tiny layer at B = 256 -- two waves per SIMD).
+bool attention_log2q_enabled() {
+  static const bool off = getenv("GWW_ATT_LOG2Q") && atoi(getenv("GWW_ATT_LOG2Q")) == 0;
+  return !off;
+}
+static bool attention_pipe_kernel() {
   static const bool on = getenv("GWW_ATT_PIPE") && atoi(getenv("GWW_ATT_PIPE")) != 0;
   return on;
 }
@@ -637,28 +894,34 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
   GWW_REQUIRE(B >= 0 && T > 0 && H > 0, "attention_bf16: bad shape B=%d T=%d H=%d", B, T, H);
   GWW_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)ctx) & 15) == 0, "attention_bf16: 16-byte alignment");
   if (B == 0) return GWW_OK;
-  static const int nw_env = getenv("GWW_ATT_WAVES") ? atoi(getenv("GWW_ATT_WAVES")) : 0;   // tuning aid: 4 or 8
+  const int nw_env = getenv("GWW_ATT_WAVES") ? atoi(getenv("GWW_ATT_WAVES")) : 0;   // tuning aid: 4 or 8 (read per call)
   // 128 query rows per workgroup, two workgroups per CU; the 256-row form (one per CU, K / V streamed once per
   // 256 queries) measures 5 % slower at T = 1500 -- the kernel is issue-bound, not L2-bound
-  const int nw = (nw_env == 8 && !q_log2) ? 8 : 4;
+  const bool pipe = q_log2 && attention_pipe_kernel();
+  const int nw = (nw_env == 8 && !pipe) ? 8 : 4;
   static const int mb_env = getenv("GWW_ATT_MB") ? atoi(getenv("GWW_ATT_MB")) : 1;   // pipelined kernel: row blocks per wave
-  const int mb = q_log2 ? (mb_env == 2 ? 2 : 1) : 1;
+  const int mb = pipe ? (mb_env == 2 ? 2 : 1) : 1;
   const int all_tiles = (T + nw * 32 * mb - 1) / (nw * 32 * mb);
   const int q_tiles = last_tile_only ? 1 : all_tiles, qt0 = last_tile_only ? all_tiles - 1 : 0;
   const long blocks = (long)q_tiles * B * H;
   GWW_REQUIRE(blocks < 2147483647L, "attention_bf16: grid too large");
-  if (q_log2 && mb == 2)
-    hipLaunchKernelGGL((k_attention_pipe_bf16<4, 2>), dim3((unsigned)blocks), dim3(256), 0, s,
-                       (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles, qt0);
-  else if (q_log2)
-    hipLaunchKernelGGL((k_attention_pipe_bf16<4, 1>), dim3((unsigned)blocks), dim3(256), 0, s,
-                       (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles, qt0);
+  const unsigned short* in = (const unsigned short*)qkv;
+  unsigned short* out = (unsigned short*)ctx;
+  if (pipe && mb == 2)
+    hipLaunchKernelGGL((k_attention_pipe_bf16<4, 2>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0);
+  else if (pipe)
+    hipLaunchKernelGGL((k_attention_pipe_bf16<4, 1>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0);
+  else if (q_log2) {
+    const int var = getenv("GWW_ATT_VAR") ? atoi(getenv("GWW_ATT_VAR")) & 3 : 0;   // read per call: in-process A/B
+#define GWW_L2(NWW, VV) hipLaunchKernelGGL((k_attention_l2_bf16<NWW, VV>), dim3((unsigned)blocks), dim3(NWW * 64), 0, s, in, out, lse, T, H, q_tiles, qt0)
+    if (nw == 8) { if (var == 0) GWW_L2(8, 0); else if (var == 1) GWW_L2(8, 1); else if (var == 2) GWW_L2(8, 2); else GWW_L2(8, 3); }
+    else { if (var == 0) GWW_L2(4, 0); else if (var == 1) GWW_L2(4, 1); else if (var == 2) GWW_L2(4, 2); else GWW_L2(4, 3); }
+#undef GWW_L2
+  }
   else if (nw == 8)
-    hipLaunchKernelGGL(k_attention_bf16<8>, dim3((unsigned)blocks), dim3(512), 0, s,
-                       (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles, qt0);
+    hipLaunchKernelGGL(k_attention_bf16<8>, dim3((unsigned)blocks), dim3(512), 0, s, in, out, lse, T, H, q_tiles, qt0);
   else
-    hipLaunchKernelGGL(k_attention_bf16<4>, dim3((unsigned)blocks), dim3(256), 0, s,
-                       (const unsigned short*)qkv, (unsigned short*)ctx, lse, T, H, q_tiles, qt0);
+    hipLaunchKernelGGL(k_attention_bf16<4>, dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }

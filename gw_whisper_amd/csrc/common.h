@@ -116,7 +116,7 @@ int launch_gemm_f32(const float* A, long lda, const float* W, const float* bias,
                     hipStream_t s);
 int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipStream_t s, float* lse = nullptr,
                           bool last_tile_only = false, bool q_log2 = false);
-bool attention_pipe_enabled();
+bool attention_log2q_enabled();   // the inference path packs q in log2 units (attention.hip)
 int launch_attention_f32(const float* qkv, float* ctx, int B, int T, int H, hipStream_t s);
 int launch_conv1_bf16(const float* mel, const void* w_packed, const float* bias, void* out,
                       int B, int T, int n_mels, int d, hipStream_t s);

@@ -299,9 +299,9 @@ static int pack_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_
       GWW_TRY(launch_scale_copy(L.ln1_w, w.ln1w, d, 1.f, s));
       GWW_TRY(launch_scale_copy(L.ln1_b, w.ln1b, d, 1.f, s));
       // gain-folded panel + correction vectors for the algebraic LayerNorm of the A-stationary GEMM
-      // (the A-stationary inference path feeds the software-pipelined attention kernel, which takes q in log2
-      // units: log2(e) rides in the q panel, one rounding of the fp32 product instead of a second one on bf16 q)
-      GWW_TRY(launch_ln_fold(L.q_w, L.ln1_w, L.ln1_b, L.q_b, attention_pipe_enabled() ? qs * 1.44269504088896340736f : qs,
+      // (the A-stationary inference path feeds k_attention_l2_bf16, which takes q in log2 units: log2(e) rides in
+      // the q panel, one rounding of the fp32 product instead of a second one on bf16 q)
+      GWW_TRY(launch_ln_fold(L.q_w, L.ln1_w, L.ln1_b, L.q_b, attention_log2q_enabled() ? qs * 1.44269504088896340736f : qs,
                              d, d, w.wqkv_ln, w.uqkv, w.cbqkv, s));
       GWW_TRY(launch_ln_fold(L.k_w, L.ln1_w, L.ln1_b, nullptr, 1.f, d, d, w.wqkv_ln + dd, w.uqkv + d, w.cbqkv + d, s));
       GWW_TRY(launch_ln_fold(L.v_w, L.ln1_w, L.ln1_b, L.v_b, 1.f, d, d, w.wqkv_ln + 2 * dd, w.uqkv + 2 * d,
@@ -507,7 +507,7 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   else
     TR(TR_CONV2, gemm(c1, 2L * d, e->c2w, e->c2w32, e->c2b, nullptr, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2,
                       T + 1));
-  const bool q_log2 = attention_pipe_enabled();   // the LN-folded q panel carries log2(e) (pack_weights)
+  const bool q_log2 = attention_log2q_enabled();   // the LN-folded q panel carries log2(e) (pack_weights)
   float* xc = x;                       // current residual stream
   const void* pending = nullptr;       // bf16 delta not yet added to xc (A-stationary path)
   if (astat) {

@@ -285,11 +285,24 @@ def _attn_ref_log2q(qkv_l2, H):
     return o.transpose(0, 2, 1, 3).reshape(B, Tn, d)
 
 
+@pytest.fixture(params=["l2", "l2_var1", "l2_var2", "l2_var3", "l2_8waves"])
+def att_variant(request, monkeypatch):
+    """k_attention_l2_bf16 (the inference path's kernel) and its tuning variants; the launcher reads GWW_ATT_VAR /
+    GWW_ATT_WAVES per call."""
+    v = request.param
+    if v.startswith("l2_var"):
+        monkeypatch.setenv("GWW_ATT_VAR", v[-1])
+    elif v == "l2_8waves":
+        monkeypatch.setenv("GWW_ATT_WAVES", "8")
+    return v
+
+
 @pytest.mark.parametrize("B,Tn,H", [(1, 64, 1), (1, 37, 1), (2, 200, 2), (1, 128, 1), (1, 192, 2), (1, 1500, 2),
-                                    (3, 129, 6), (2, 257, 1)])
-def test_attention_pipelined_log2q(T, gww, B, Tn, H):
-    """The software-pipelined kernel (scores of tile j+1 beside the softmax of tile j; q in log2 units): one, two,
-    three ... tiles, ragged and full last tiles, and the log-sum-exp it hands to training-style consumers."""
+                                    (3, 129, 6), (2, 257, 1), (1, 1, 1), (2, 65, 2)])
+def test_attention_pipelined_log2q(T, gww, att_variant, B, Tn, H):
+    """The log2-unit-q kernel (reference through the matrix pipe, first tile re-based, deferred re-basing later):
+    one, two, three ... tiles, ragged and full last tiles, a single key, and the log-sum-exp it hands to
+    training-style consumers."""
     from gw_whisper_amd import ops
     rng = np.random.default_rng(B * 1000 + Tn + H)
     qkv = _to_log2q(_bf(rng.standard_normal((B, Tn, 3 * H * 64)) * 0.7))
@@ -306,7 +319,40 @@ def test_attention_pipelined_log2q(T, gww, B, Tn, H):
         np.testing.assert_allclose(lse[:, h].cpu().numpy(), ref_lse, atol=2e-2, rtol=1e-3)
 
 
-def test_attention_pipelined_spike_forces_rebase(T, gww):
+@pytest.mark.parametrize("offset", [-100.0, -12.0, 0.0, 9.0, 100.0])
+def test_attention_log2q_uniform_score_offsets(T, gww, att_variant, offset):
+    """Rows whose scores are ALL far below or above zero: softmax is shift-invariant, the kernel must be too (the first
+    tile is scored against reference 0 and then re-based -- 2^-144 would underflow to l = 0, 2^+144 overflow)."""
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(11)
+    H, Tn = 2, 300
+    qkv = (rng.standard_normal((1, Tn, 3 * H * 64)) * 0.4).astype(np.float32)
+    qkv[0, :, 0] = 1.0                       # q[:, 0] = 1 in head 0 ...
+    qkv[0, :, 128] = offset                  # ... and k[:, 0] = offset: every score of head 0 moves by `offset`
+    qkv = _to_log2q(_bf(qkv))
+    ref = _attn_ref_log2q(qkv, H)
+    got, lse = ops.attention_log2q(T.from_numpy(qkv).cuda().bfloat16(), H, want_lse=True)
+    assert T.isfinite(got).all() and T.isfinite(lse).all()
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=6e-3, rtol=2 ** -7)
+
+
+def test_attention_log2q_staircase_rebases_at_every_tile(T, gww, att_variant):
+    """The best key of every query moves up by ~14 (natural units, above the deferral threshold) from each 64-key tile
+    to the next: a re-base in every tile, nine in a row."""
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(12)
+    H, Tn = 1, 600
+    qkv = (rng.standard_normal((1, Tn, 192)) * 0.2).astype(np.float32)
+    qkv[0, :, 0] = 1.0
+    qkv[0, :, 64] = 14.0 * (np.arange(Tn) // 64)          # k[:, 0]: staircase over the key tiles
+    qkv = _to_log2q(_bf(qkv))
+    ref = _attn_ref_log2q(qkv, H)
+    got = ops.attention_log2q(T.from_numpy(qkv).cuda().bfloat16(), H).float().cpu().numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, ref, atol=6e-3, rtol=2 ** -7)
+
+
+def test_attention_pipelined_spike_forces_rebase(T, gww, att_variant):
     """A key far above the running reference late in the sequence (score 256): O, l AND the scores of the tile
     computed against the old reference must move to the new one; then a long tail of small scores."""
     from gw_whisper_amd import ops
