@@ -416,7 +416,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void k_attention_l2_bf16(
     for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int j = 0; j < 16; ++j) tmax = fmaxf(tmax, st[g][j]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    {   // the other 32 keys of the row sit in lane ^ 32: one v_permlane32_swap instead of an LDS round trip (ds_bpermute)
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+      tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
     if (FIRST || __builtin_amdgcn_ballot_w64(tmax > kDeferL2) != 0) {   // wave-uniform, rare after the first tile
       // move the reference of every row that needs it: the new one is what the bf16 pair can represent
       const float want = m_run + (FIRST ? tmax : fmaxf(tmax, 0.f));

@@ -45,12 +45,17 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #ifndef GWW_MF_AHEAD
 #define GWW_MF_AHEAD 6
 #endif
-constexpr int MF_AHEAD = GWW_MF_AHEAD, MF_NST = MF_AHEAD + 1;   // tiles in flight ahead of the one being computed, ring stages
+constexpr int MF_AHEAD = GWW_MF_AHEAD;   // tiles in flight ahead of the one being computed
+// Ring slots.  PAIR = false: AHEAD + 1 slots, one s_barrier per 16-KiB tile.  PAIR = true: AHEAD + 2 slots and ONE
+// barrier per TWO tiles (at the even ones): the wait in front of it leaves 3 tiles in flight, so tiles it, it + 1 and
+// it + 2 (whose first fragments are prefetched in the last step of tile it + 1) have landed for every wave; the DMA
+// issued during tile it (it + 1) overwrites the slot of tile it - 2 (it - 1), which every wave left before that barrier.
+constexpr int MF_NST_MAX = MF_AHEAD + 2;
 constexpr int MF_TILE = 128 * 64 * 2;      // 16 KB
 constexpr int MF_GL = 16 / MF_WAVES;       // LDS-DMA pieces per thread per tile
 constexpr int MF_FMAX = 1536;              // largest ffn (cb / u staged in LDS)
 constexpr int MF_SLICE_STRIDE = 144, MF_SLICE_BYTES = 32 * MF_SLICE_STRIDE;
-constexpr int MF_OFF_CB = MF_NST * MF_TILE;
+constexpr int MF_OFF_CB = MF_NST_MAX * MF_TILE;
 constexpr int MF_OFF_U = MF_OFF_CB + MF_FMAX * 4;
 constexpr int MF_OFF_B2 = MF_OFF_U + MF_FMAX * 4;
 constexpr int MF_OFF_SLICE = MF_OFF_B2 + MF_D * 4;
@@ -101,7 +106,7 @@ __device__ unsigned long long g_stamp_mlp[24];
 // while the output is still in registers; the 192 output-accumulator registers are free by then), whose weight
 // tiles simply continue the same stream.  The standalone LN+QKV kernel's 10 B/element HBM round trip of the
 // residual stream disappears.
-template <bool QKV>
+template <bool QKV, bool PAIR>
 __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, const unsigned short* delta, float* x_out,
                                                             const float* __restrict__ ln_u,
                                                             const float* __restrict__ ln_cb,
@@ -112,6 +117,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
                                                             const float* __restrict__ q_cb,
                                                             unsigned short* __restrict__ q_out, int NQ) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[MF_LDS];
+  constexpr int MF_NST = PAIR ? MF_AHEAD + 2 : MF_AHEAD + 1;
   float* lds_cb = reinterpret_cast<float*>(lds + MF_OFF_CB);
   float* lds_u = reinterpret_cast<float*>(lds + MF_OFF_U);
   float* lds_b2 = reinterpret_cast<float*>(lds + MF_OFF_B2);
@@ -342,12 +348,14 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   // KIND 1: fc2 tile ng with P = pf[2 PAR + ..].  ride_t >= 0: S index whose GELU values ride in this tile
   // (values v0 .. of its four pieces, 16 per S index, spread 1-1-2 over the 12 steps of a phase);
   // next_kind: kind of the tile that follows (its first fragments are prefetched in the last step).
-  auto run_tile = [&](auto kind_c, auto par_c, auto idx3_c, int cpair, auto ride_t_c, int ride_cpair, int next_kind) {
+  auto run_tile = [&](auto kind_c, auto par_c, auto idx3_c, auto bar_c, auto ride_t_c, int ride_cpair, int next_kind) {
     constexpr int KIND = decltype(kind_c)::value, PAR = decltype(par_c)::value, IDX3 = decltype(idx3_c)::value;
     constexpr int RIDE_T = decltype(ride_t_c)::value;
-    (void)cpair;
-    mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
-    __builtin_amdgcn_s_barrier();
+    constexpr bool BAR = !PAIR || decltype(bar_c)::value != 0;   // PAIR: barrier at the even tiles only
+    if constexpr (BAR) {
+      mf_wait_vmcnt<PAIR ? MF_GL * 3 : MF_GL * (MF_AHEAD - 2)>();
+      __builtin_amdgcn_s_barrier();
+    }
     MSTAMP(1);
     const int dma_tile = it + MF_AHEAD < total ? it + MF_AHEAD : total - 1;
     const int dma_stage = stage + MF_AHEAD >= MF_NST ? stage + MF_AHEAD - MF_NST : stage + MF_AHEAD;
@@ -425,41 +433,41 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   using IM = std::integral_constant<int, -1>;
 
   // G1(0): no GELU to carry yet; its first half is then computed in the open (once per 128 rows)
-  run_tile(I0{}, I0{}, I0{}, 0, IM{}, 0, 0);
-  run_tile(I0{}, I0{}, I1{}, 0, IM{}, 0, 0);
-  run_tile(I0{}, I0{}, I2{}, 0, IM{}, 0, 0);
+  run_tile(I0{}, I0{}, I0{}, I1{}, IM{}, 0, 0);
+  run_tile(I0{}, I0{}, I1{}, I0{}, IM{}, 0, 0);
+  run_tile(I0{}, I0{}, I2{}, I1{}, IM{}, 0, 0);
   act_piece(0, 0, 0); act_piece(0, 0, 1); act_piece(0, 0, 2); act_piece(0, 0, 3);
   int b = 0;
   for (; b + 2 < nck; b += 2) {
     // ---- block b (parity 0): G1(b + 1) -> S[2..3] carrying the second half of GELU(b) (S[1]);
     //      G2(b) with pf[0..1] carrying the first half of GELU(b + 1) (S[2])
-    run_tile(I0{}, I1{}, I0{}, 0, I1{}, b >> 1, 0);
-    run_tile(I0{}, I1{}, I1{}, 0, I1{}, b >> 1, 0);
-    run_tile(I0{}, I1{}, I2{}, 0, I1{}, b >> 1, 1);
-    run_tile(I1{}, I0{}, I0{}, 0, I2{}, b >> 1, 1);
-    run_tile(I1{}, I0{}, I1{}, 0, I2{}, b >> 1, 1);
-    run_tile(I1{}, I0{}, I2{}, 0, I2{}, b >> 1, 0);
+    run_tile(I0{}, I1{}, I0{}, I0{}, I1{}, b >> 1, 0);
+    run_tile(I0{}, I1{}, I1{}, I1{}, I1{}, b >> 1, 0);
+    run_tile(I0{}, I1{}, I2{}, I0{}, I1{}, b >> 1, 1);
+    run_tile(I1{}, I0{}, I0{}, I1{}, I2{}, b >> 1, 1);
+    run_tile(I1{}, I0{}, I1{}, I0{}, I2{}, b >> 1, 1);
+    run_tile(I1{}, I0{}, I2{}, I1{}, I2{}, b >> 1, 0);
     // ---- block b + 1 (parity 1): G1(b + 2) -> S[0..1] carrying the second half of GELU(b + 1) (S[3]);
     //      G2(b + 1) with pf[2..3] carrying the first half of GELU(b + 2) (S[0])
-    run_tile(I0{}, I0{}, I0{}, 0, I3{}, b >> 1, 0);
-    run_tile(I0{}, I0{}, I1{}, 0, I3{}, b >> 1, 0);
-    run_tile(I0{}, I0{}, I2{}, 0, I3{}, b >> 1, 1);
-    run_tile(I1{}, I1{}, I0{}, 0, I0{}, (b >> 1) + 1, 1);
-    run_tile(I1{}, I1{}, I1{}, 0, I0{}, (b >> 1) + 1, 1);
-    run_tile(I1{}, I1{}, I2{}, 0, I0{}, (b >> 1) + 1, 0);
+    run_tile(I0{}, I0{}, I0{}, I0{}, I3{}, b >> 1, 0);
+    run_tile(I0{}, I0{}, I1{}, I1{}, I3{}, b >> 1, 0);
+    run_tile(I0{}, I0{}, I2{}, I0{}, I3{}, b >> 1, 1);
+    run_tile(I1{}, I1{}, I0{}, I1{}, I0{}, (b >> 1) + 1, 1);
+    run_tile(I1{}, I1{}, I1{}, I0{}, I0{}, (b >> 1) + 1, 1);
+    run_tile(I1{}, I1{}, I2{}, I1{}, I0{}, (b >> 1) + 1, 0);
   }
   // ---- last pair (b = n - 2): G1(n - 1) + second half of GELU(n - 2); G2(n - 2) + first half of GELU(n - 1);
   //      then the second half of GELU(n - 1) in the open (nothing left to hide it under) and G2(n - 1)
-  run_tile(I0{}, I1{}, I0{}, 0, I1{}, b >> 1, 0);
-  run_tile(I0{}, I1{}, I1{}, 0, I1{}, b >> 1, 0);
-  run_tile(I0{}, I1{}, I2{}, 0, I1{}, b >> 1, 1);
-  run_tile(I1{}, I0{}, I0{}, 0, I2{}, b >> 1, 1);
-  run_tile(I1{}, I0{}, I1{}, 0, I2{}, b >> 1, 1);
-  run_tile(I1{}, I0{}, I2{}, 0, I2{}, b >> 1, 1);
+  run_tile(I0{}, I1{}, I0{}, I0{}, I1{}, b >> 1, 0);
+  run_tile(I0{}, I1{}, I1{}, I1{}, I1{}, b >> 1, 0);
+  run_tile(I0{}, I1{}, I2{}, I0{}, I1{}, b >> 1, 1);
+  run_tile(I1{}, I0{}, I0{}, I1{}, I2{}, b >> 1, 1);
+  run_tile(I1{}, I0{}, I1{}, I0{}, I2{}, b >> 1, 1);
+  run_tile(I1{}, I0{}, I2{}, I1{}, I2{}, b >> 1, 1);
   act_piece(0, b >> 1, 12); act_piece(0, b >> 1, 13); act_piece(0, b >> 1, 14); act_piece(0, b >> 1, 15);
-  run_tile(I1{}, I1{}, I0{}, 0, IM{}, 0, 1);
-  run_tile(I1{}, I1{}, I1{}, 0, IM{}, 0, 1);
-  run_tile(I1{}, I1{}, I2{}, 0, IM{}, 0, QKV ? 2 : 1);
+  run_tile(I1{}, I1{}, I0{}, I0{}, IM{}, 0, 1);
+  run_tile(I1{}, I1{}, I1{}, I1{}, IM{}, 0, 1);
+  run_tile(I1{}, I1{}, I2{}, I0{}, IM{}, 0, QKV ? 2 : 1);
 
   if constexpr (!QKV) {
     mf_wait_vmcnt<0>();   // the re-reads issued past the end
@@ -621,9 +629,17 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       for (int kt = 0; kt < MF_KT; ++kt) {
         // the 8 output stores of the previous n-tile are younger than the DMA group being waited for while
         // kt <= 4 (that group was issued 5 tiles ago): allow them to stay in flight
-        if (nt > 0 && kt != MF_KT - 1) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + 8>();
-        else mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!PAIR) {
+          if (nt > 0 && kt != MF_KT - 1) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + 8>();
+          else mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
+          __builtin_amdgcn_s_barrier();
+        } else if (kt % 2 == 0) {
+          // queue at (nt, 0): [DMA it+3 .. it+5][8 stores]; at (nt, 2): [DMA it+3][8 stores][DMA it+4, it+5]; at (nt, 4) the
+          // stores are older than everything that may stay in flight
+          if (nt > 0 && kt <= 2) mf_wait_vmcnt<MF_GL * 3 + 8>();
+          else mf_wait_vmcnt<MF_GL * 3>();
+          __builtin_amdgcn_s_barrier();
+        }
         const int itq = T0 + nt * MF_KT + kt;
         const int dma_tile = itq + MF_AHEAD < total ? itq + MF_AHEAD : total - 1;
         const int dma_stage = stage + MF_AHEAD >= MF_NST ? stage + MF_AHEAD - MF_NST : stage + MF_AHEAD;
@@ -784,14 +800,18 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
   // stagger only when there is more than one round of workgroups to keep de-phased; 100 MHz ticks
   static const int stagger_env = getenv("GWW_MLP_STAGGER") ? atoi(getenv("GWW_MLP_STAGGER")) : 0;
   const int stagger = panels >= 512 ? stagger_env : 0;
-  if (qkv)
-    hipLaunchKernelGGL(k_mlp_fused<true>, dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta,
-                       x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger, q_u, q_cb,
-                       (unsigned short*)q_out, NQ);
-  else
-    hipLaunchKernelGGL(k_mlp_fused<false>, dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta,
-                       x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger, nullptr,
-                       nullptr, nullptr, 0);
+  const bool pair = !(getenv("GWW_MLP_PAIR") && atoi(getenv("GWW_MLP_PAIR")) == 0);   // read per call: in-process A/B
+#define GWW_MF_LAUNCH(QQ, PP, ...)                                                                                         \
+  hipLaunchKernelGGL((k_mlp_fused<QQ, PP>), dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta, \
+                     x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger, __VA_ARGS__)
+  if (qkv) {
+    if (pair) GWW_MF_LAUNCH(true, true, q_u, q_cb, (unsigned short*)q_out, NQ);
+    else GWW_MF_LAUNCH(true, false, q_u, q_cb, (unsigned short*)q_out, NQ);
+  } else {
+    if (pair) GWW_MF_LAUNCH(false, true, nullptr, nullptr, nullptr, 0);
+    else GWW_MF_LAUNCH(false, false, nullptr, nullptr, nullptr, 0);
+  }
+#undef GWW_MF_LAUNCH
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }

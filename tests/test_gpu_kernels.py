@@ -447,8 +447,16 @@ def test_mlp_pack_layout(T, gww):
                 np.testing.assert_array_equal(logical, w2n[128 * idx3 + row, 64 * cp:64 * cp + 64][sw])
 
 
+@pytest.fixture(params=["pair", "single"])
+def mlp_ring(request, monkeypatch):
+    """Both ring disciplines of k_mlp_fused: one s_barrier per two weight tiles (default) and per tile (GWW_MLP_PAIR=0)."""
+    if request.param == "single":
+        monkeypatch.setenv("GWW_MLP_PAIR", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("M,F", [(128, 128), (1500, 1536), (777, 512), (4000, 1536), (70000, 1536)])
-def test_mlp_fused(T, gww, M, F):
+def test_mlp_fused(T, gww, mlp_ring, M, F):
     """LayerNorm -> fc1 -> GELU -> fc2 of (x + delta) in one kernel (mlp_fused.hip) against fp64:
     HF:modeling_whisper.py:401-407 without the residual add (deferred to the consumer)."""
     from gw_whisper_amd import ops
@@ -478,7 +486,7 @@ def test_mlp_fused(T, gww, M, F):
 
 
 @pytest.mark.parametrize("M", [128, 1500, 4000])
-def test_mlp_fused_with_next_layers_qkv(T, gww, M):
+def test_mlp_fused_with_next_layers_qkv(T, gww, mlp_ring, M):
     """mlp_fused with the NEXT layer's LayerNorm1 + q / k / v projection appended: x_next = x + delta + bf16(mlp),
     qkv = Linear_qkv(LayerNorm1(x_next)) -- against fp64 (HF:modeling_whisper.py:392-407 across the layer seam)."""
     from gw_whisper_amd import ops

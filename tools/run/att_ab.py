@@ -13,7 +13,7 @@ arms = {"old(natural q)": (None, None, ops.attention)}
 for v in range(4):
     arms[f"l2 var{v}"] = (str(v), None, ops.attention_log2q)
 arms["l2 var0 8waves"] = ("0", "8", ops.attention_log2q)
-arms["l2 var1 8waves"] = ("1", "8", ops.attention_log2q)
+arms["l2 var2 8waves"] = ("2", "8", ops.attention_log2q)
 times = {k: [] for k in arms}
 def run(name):
     var, waves, fn = arms[name]

@@ -63,3 +63,36 @@ for pn, g in grads.items():
     fd = (vals[0] - vals[1]) / (2 * eps)
     an = float((g.double() * v.double()).sum())
     print(f"{pn.replace('base_model.model.', ''):62s} an {an:12.4f} fd {fd:12.4f} rel {abs(an - fd) / (abs(fd) + 1e-12):7.4f}  |g|max {g.abs().max().item():.3e}")
+
+# ---- optional: element-wise finite differences of ONE tensor (FULL=<substring of its name>)
+full = os.environ.get("FULL")
+if full:
+    pn = [n for n in grads if full in n][0]
+    tgt = pn.split(".lora_")[0].replace("base_model.model.", "")
+    p, g = params[pn], grads[pn]
+    mag = params[pn.split(".lora_")[0] + ".lora_magnitude_vector.default.weight"]
+    fdg = T.zeros_like(g, dtype=T.float64)
+    flat = p.data.view(-1)
+    e2 = float(os.environ.get("EPS2", "1e-2"))
+    for i in range(flat.numel()):
+        vals = []
+        for sgn in (+1, -1):
+            with T.no_grad():
+                flat[i] += sgn * e2
+                keep = mag.detach().clone()
+                if "magnitude" not in pn:
+                    mag.mul_((norms()[tgt] / n0[tgt]).float())
+                vals.append(loss32())
+                mag.copy_(keep)
+                flat[i] -= sgn * e2
+        fdg.view(-1)[i] = (vals[0] - vals[1]) / (2 * e2)
+    gd = g.double()
+    cos = float((gd * fdg).sum() / (gd.norm() * fdg.norm()))
+    scale = float((gd * fdg).sum() / (fdg * fdg).sum())
+    print(f"FULL {pn}: cosine {cos:.5f}  least-squares scale g_hip / g_fd {scale:.4f}  |g_hip - g_fd| / |g_fd| {float((gd - fdg).norm() / fdg.norm()):.4f}")
+    r = (gd - fdg)
+    if r.dim() == 2:
+        print("  relative residual per row   :", [round(float(r[i].norm() / fdg[i].norm()), 3) for i in range(min(r.shape[0], 8))])
+        cols = r.norm(dim=0) / (fdg.norm(dim=0) + 1e-30)
+        print("  relative residual per column: min %.3f median %.3f max %.3f" % (float(cols.min()), float(cols.median()), float(cols.max())))
+        print("  g_hip[0,:6]", gd[0, :6].tolist()); print("  g_fd [0,:6]", fdg[0, :6].tolist())
