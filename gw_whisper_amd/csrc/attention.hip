@@ -528,6 +528,235 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void k_attention_l2_bf16(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// LDS-DMA form of k_attention_l2_bf16 (GWW_ATT_VAR = 4 / 5): K / V tiles go global -> LDS directly
+// (global_load_lds_dwordx4, the XOR swizzles applied on the per-lane SOURCE address, the LDS image stays lane-linear),
+// so there are no staging registers (16 VGPRs) and no ds_write_b128 (4 per wave and tile, 13 issue cycles each); the
+// softmax denominator is summed on the VALU (no ones-MFMA accumulator: another 16 VGPRs).  The kernel then fits 128
+// registers, i.e. FOUR waves per SIMD (MINW = 4) instead of three: the loop is bound by issue stalls that more
+// resident waves can fill (PMC: something issues only 70 % of the cycles at three waves).
+// Two LDS buffers: the DMA of tile kt + 1 is issued at the top of tile kt into the buffer tile kt - 1 used (every wave
+// left it before the barrier that ended tile kt - 1); __syncthreads() at the end of the tile is vmcnt(0) + s_barrier
+// (hipcc drains LDS-DMA in front of it), after which the tile is visible to every wave.
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned short* __restrict__ qkv,
+                                                                 unsigned short* __restrict__ ctx,
+                                                                 float* __restrict__ lse, int T, int H, int q_tiles,
+                                                                 int qt0) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KB * DH * 2];   // K0 | K1 | V0 | V1, 8 KB each
+  constexpr int TILE_BYTES = KB * DH * 2, NW = 4;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* g_ptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned nblk = gridDim.x, per = nblk >> 3;
+  const unsigned wid = blockIdx.x < 8 * per ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;   // XCD-aware order
+  const int qt = qt0 + wid % q_tiles;
+  const int bh = wid / q_tiles;
+  const int b = bh / H, h = bh - b * H;
+  const int d = H * DH;
+  const long row_stride = 3L * d;
+  const unsigned short* base = qkv + (long)b * T * row_stride;
+  const unsigned short* qp = base + h * DH;
+  const unsigned short* kp = base + d + h * DH;
+  const unsigned short* vp = base + 2 * d + h * DH;
+  const int r = lane & 31, hh = lane >> 5;
+  const int q_row = qt * (NW * 32) + wave * 32 + r;
+  const int q_ld = q_row < T ? q_row : T - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + (long)q_ld * row_stride + 16 * s + 8 * hh);
+
+  // ---- DMA roles: piece j (0, 1) of this wave = tile rows 8 (2 wave + j) .. + 7; lane l lands at LDS (row l >> 3,
+  // 16-byte position l & 7), which must hold the chunk the swizzled reads expect there
+  const int n_kt = (T + KB - 1) / KB;
+  const bool ragged = (T % KB) != 0;
+  unsigned koff[2], voff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 8 * (2 * wave + j) + (lane >> 3), pos = lane & 7;
+    koff[j] = (unsigned)(row * (int)row_stride * 2 + ((pos ^ ((row >> 1) & 7)) << 4));
+    voff[j] = (unsigned)(row * (int)row_stride * 2 + ((pos ^ (((row >> 1) & 1) << 2)) << 4));
+  }
+  auto dma = [&](int kt, auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+    const char* kb = reinterpret_cast<const char*>(kp + (long)kt * KB * row_stride);   // wave-uniform
+    const char* vb = reinterpret_cast<const char*>(vp + (long)kt * KB * row_stride);
+    unsigned char* dk = lds + BUF * TILE_BYTES + (2 * wave_u) * 1024;
+    unsigned char* dv = dk + 2 * TILE_BYTES;
+    if (kt != n_kt - 1 || !ragged) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        __builtin_amdgcn_global_load_lds((g_ptr)(kb + koff[j]), (lds_ptr)(dk + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((g_ptr)(vb + voff[j]), (lds_ptr)(dv + j * 1024), 16, 0, 0);
+      }
+    } else {   // ragged last tile: rows past T - 1 read row T - 1 (masked afterwards; never past the tensor)
+      const int last_row = T - 1 - kt * KB;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = 8 * (2 * wave + j) + (lane >> 3), pos = lane & 7;
+        const int rc = row < last_row ? row : last_row;
+        const unsigned ko = (unsigned)(rc * (int)row_stride * 2 + ((pos ^ ((row >> 1) & 7)) << 4));
+        const unsigned vo = (unsigned)(rc * (int)row_stride * 2 + ((pos ^ (((row >> 1) & 1) << 2)) << 4));
+        __builtin_amdgcn_global_load_lds((g_ptr)(kb + ko), (lds_ptr)(dk + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((g_ptr)(vb + vo), (lds_ptr)(dv + j * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+  const int tr_colbyte = (((lane & 31) >> 4) * 16 + 4 * tr_p) * 2;
+  const unsigned char* kbase[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) kbase[s] = lds + k_off(r, 2 * s + hh);
+  const unsigned char* vbase[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) vbase[n] = lds + 2 * TILE_BYTES + v_off(4 * hh + tr_q, 64 * n + tr_colbyte);
+
+  f32x16 ot[2];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { ot[0][j] = 0.f; ot[1][j] = 0.f; }
+  bf16x8 ones, mref;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ones[j] = (__bf16)1.0f; mref[j] = (__bf16)0.0f; }
+  float l_run = 0.f, m_run = 0.f;
+  constexpr float kDeferL2 = 8.0f * kLog2e;
+  typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+
+  auto tile = [&](int kt, auto buf_c, auto first_c, auto masked_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+    constexpr bool FIRST = decltype(first_c)::value, MASKED = decltype(masked_c)::value;
+    if (kt + 1 < n_kt) dma(kt + 1, std::integral_constant<int, BUF ^ 1>{});
+    f32x16 st[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f32x16 z;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) z[j] = 0.f;
+      if constexpr (FIRST) st[g] = z;
+      else st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, mref, z, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase[s] + BUF * TILE_BYTES + g * (32 * 128));
+        st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[g], 0, 0, 0);
+      }
+    }
+    if constexpr (MASKED) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int key = kt * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
+          if (key >= T) st[g][j] = -INFINITY;
+        }
+    }
+    float tmax = st[0][0];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tmax = fmaxf(tmax, st[g][j]);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+      tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    if (FIRST || __builtin_amdgcn_ballot_w64(tmax > kDeferL2) != 0) {
+      const float want = m_run + (FIRST ? tmax : fmaxf(tmax, 0.f));
+      const __bf16 hi = (__bf16)(-want);
+      const __bf16 lo = (__bf16)(-want - (float)hi);
+      const float m_new = -((float)hi + (float)lo);
+      const float dm = m_new - m_run;
+      const float alpha = __builtin_amdgcn_exp2f(-dm);
+      m_run = m_new;
+      if constexpr (!FIRST) l_run *= alpha;
+      mref[0] = hh == 0 ? hi : (__bf16)0.0f;
+      mref[1] = hh == 0 ? lo : (__bf16)0.0f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if constexpr (!FIRST) {
+          ot[0][j] *= alpha;
+          ot[1][j] *= alpha;
+        }
+        st[0][j] -= dm;
+        st[1][j] -= dm;
+      }
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        st[g][j] = __builtin_amdgcn_exp2f(st[g][j]);
+        ps += st[g][j];
+      }
+    l_run += ps;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = cvt8(st[g], 8 * s);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const unsigned char* vb = vbase[n] + BUF * TILE_BYTES + (32 * g + 16 * s) * 128;
+          const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)vb);
+          const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vb + 8 * 128));
+          bf16x8 vf;
+          vf[0] = lo4[0]; vf[1] = lo4[1]; vf[2] = lo4[2]; vf[3] = lo4[3];
+          vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
+          ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[n], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();   // vmcnt(0): this wave's pieces of tile kt + 1 have landed; barrier: everybody's have
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using Yes = std::true_type;
+  using No = std::false_type;
+
+  dma(0, P0{});
+  __syncthreads();
+  if (n_kt == 1) {
+    if (ragged) tile(0, P0{}, Yes{}, Yes{});
+    else tile(0, P0{}, Yes{}, No{});
+  } else {
+    tile(0, P0{}, Yes{}, No{});
+    int kt = 1;
+    for (; kt + 2 <= n_kt - 1; kt += 2) {
+      tile(kt, P1{}, No{}, No{});
+      tile(kt + 1, P0{}, No{}, No{});
+    }
+    if (kt == n_kt - 2) {
+      tile(kt, P1{}, No{}, No{});
+      if (ragged) tile(kt + 1, P0{}, No{}, Yes{});
+      else tile(kt + 1, P0{}, No{}, No{});
+    } else {
+      if (ragged) tile(kt, P1{}, No{}, Yes{});
+      else tile(kt, P1{}, No{}, No{});
+    }
+  }
+
+  float l_tot;
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  const float inv = 1.0f / l_tot;
+  if (lse && q_row < T && hh == 0)
+    lse[((long)b * H + h) * T + q_row] = (m_run + __log2f(l_tot)) * 0.69314718055994530942f;
+  if (q_row < T) {
+    unsigned short* orow = ctx + ((long)b * T + q_row) * d + h * DH;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int dh = 32 * n + 8 * c + 4 * hh;
+        u32x2 o = {pack2bf(ot[n][4 * c] * inv, ot[n][4 * c + 1] * inv),
+                   pack2bf(ot[n][4 * c + 2] * inv, ot[n][4 * c + 3] * inv)};
+        *reinterpret_cast<u32x2*>(orow + dh) = o;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Software-pipelined form of the same kernel (experimental: GWW_ATT_PIPE=1 makes the encoder use it).
 // The kernel above runs S = K Q^T, the softmax VALU and the P V product of ONE tile back to back, so inside a wave
 // the matrix pipe idles through the 32 v_exp / 16 cvt / 20 max of every tile and the VALU idles through the MFMAs
@@ -915,7 +1144,15 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
   else if (pipe)
     hipLaunchKernelGGL((k_attention_pipe_bf16<4, 1>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0);
   else if (q_log2) {
-    const int var = getenv("GWW_ATT_VAR") ? atoi(getenv("GWW_ATT_VAR")) & 3 : 0;   // read per call: in-process A/B
+    const int var = getenv("GWW_ATT_VAR") ? atoi(getenv("GWW_ATT_VAR")) & 7 : 2;   // read per call: in-process A/B
+    if (var >= 4) {
+      const long blocks4 = (long)((last_tile_only ? 1 : (T + 127) / 128)) * B * H;
+      const int qt4 = last_tile_only ? (T + 127) / 128 - 1 : 0, nq4 = last_tile_only ? 1 : (T + 127) / 128;
+      if (var == 4) hipLaunchKernelGGL(k_attention_dma_bf16<3>, dim3((unsigned)blocks4), dim3(256), 0, s, in, out, lse, T, H, nq4, qt4);
+      else hipLaunchKernelGGL(k_attention_dma_bf16<4>, dim3((unsigned)blocks4), dim3(256), 0, s, in, out, lse, T, H, nq4, qt4);
+      GWW_LAUNCH_CHECK();
+      return GWW_OK;
+    }
 #define GWW_L2(NWW, VV) hipLaunchKernelGGL((k_attention_l2_bf16<NWW, VV>), dim3((unsigned)blocks), dim3(NWW * 64), 0, s, in, out, lse, T, H, q_tiles, qt0)
     if (nw == 8) { if (var == 0) GWW_L2(8, 0); else if (var == 1) GWW_L2(8, 1); else if (var == 2) GWW_L2(8, 2); else GWW_L2(8, 3); }
     else { if (var == 0) GWW_L2(4, 0); else if (var == 1) GWW_L2(4, 1); else if (var == 2) GWW_L2(4, 2); else GWW_L2(4, 3); }

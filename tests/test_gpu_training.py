@@ -287,7 +287,11 @@ def test_training_step_matches_finite_differences(T, gww, projs, enc_name):
     kinds = ["random", "aligned", "class"]
     for trial, kind in enumerate(kinds):
         if kind == "aligned":
-            v = {k: [g / (np.sqrt((g ** 2).mean()) + 1e-30) for g in gref[k]] for k in theta}
+            # per tensor: its own gradient direction, scaled to the size of the tensor's entries (the step eps * v is
+            # then 0.1 % of the parameter; a unit-rms step is 4 % of an A entry and leaves the linear regime: the
+            # element-wise check of tools/run/dbg_grad.py agrees to 0.5 % where that step reported 5 %)
+            v = {k: [g / (np.sqrt((g ** 2).mean()) + 1e-30) * np.sqrt((th ** 2).mean()) for g, th in zip(gref[k], theta[k])]
+                 for k in theta}
         else:
             v = {k: [rng.standard_normal(a.shape) for a in th] for k, th in theta.items()}
             if kind == "class":
