@@ -311,7 +311,25 @@ def main():
     qs = QScan(duration=1.0, sample_rate=2048, spectrogram_shape=[128, 128], qrange=[4, 128])
     strain2k = torch.from_numpy(synth.strain_segments(2 * B, seed=2000 + rank, n_samples=2048)).to(dev)
     q_ms = time_kernel(lambda: qs(strain2k), iters=5, warm=1)
+    # the whole Q-transform adapter of BASELINE configs 4 / 5 (Q-scan -> small CNN (torch.nn) -> pool + affine + FiLM + stack
+    # as one HIP kernel), both variants of the reference, B two-detector windows; and that tail kernel alone
+    from gw_whisper_amd.qscan import QTransformAdapter, _AdapterTail
+    adapter_ms = {}
+    with torch.no_grad():
+        xw = strain2k.reshape(B, 2, 2048)
+        for vname, make in (("train_py_variant(128x128,32/64/128)", QTransformAdapter.train_variant),
+                            ("inference_py_variant(512x512,16/32/64)", QTransformAdapter.inference_variant)):
+            ad = make(n_detectors=2).to(dev).eval()
+            adapter_ms[vname] = time_kernel(lambda: ad(xw), iters=3, warm=1)
+            del ad
+        ycnn = torch.randn(B, 32, 32, device=dev)
+        one, zero = torch.ones(1, device=dev), torch.zeros(1, device=dev)
+        gam, bet = torch.ones(2, device=dev), torch.zeros(2, device=dev)
+        feat = torch.empty(B, 2, 80, 3000, device=dev)
+        tail_ms = time_kernel(lambda: _AdapterTail.apply(ycnn, one, zero, gam, bet, feat, 0), iters=10, warm=2)
+        del feat, ycnn, xw
     del strain2k
+    torch.cuda.empty_cache()
 
     def step():
         return enc.forward_raw(mel, want_hidden=True, want_last=True)
@@ -418,6 +436,11 @@ def main():
             "frontend_qscan": {"kernel": "rDFT GEMM + k_qscan_tiles + k_qscan_interp (parity unpinned, DESIGN.md section 2)",
                                "ms_per_batch": q_ms, "windows_per_s": 2 * B / q_ms * 1e3,
                                "config": f"{2 * B} x 2048 samples, qrange [4, 128], 148 tiles rows, 128 x 128 output"},
+            "q_adapter": {"what": f"QTransformAdapter forward on {B} two-detector windows -> [B, 2, 80, 3000] (Q-scan + torch.nn "
+                                  "CNN + gww_qadapter_tail_f32)", "ms_per_batch": adapter_ms,
+                          "tail_kernel_ms_per_detector": tail_ms,
+                          "tail_kernel_algorithmic_gbs": B * (80 * 3000 + 32 * 32) * 4 / tail_ms / 1e6,
+                          "tail_kernel_frac_of_hbm_peak": B * (80 * 3000 + 32 * 32) * 4 / tail_ms / 1e6 / HBM_PEAK_GBS},
             "pooled_classify": {"what": "encoder.last_token(): same encoder, only last_hidden_state[:, -1] produced "
                                         "(last layer: one query tile of attention, row-wise ops on B rows)",
                                 "ms_per_batch": pooled_ms, "segments_per_s_per_gpu": B / pooled_ms * 1e3}

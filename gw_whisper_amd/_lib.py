@@ -104,6 +104,11 @@ SIGNATURES = {
                                        C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p]),
     "gww_qscan_interp_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gww_qadapter_tail_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "gww_welch_power_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "gww_column_median_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
+    "gww_fir_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p]),
     "gww_gemm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gww_attention_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

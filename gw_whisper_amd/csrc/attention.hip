@@ -537,7 +537,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void k_attention_l2_bf16(
 // Two LDS buffers: the DMA of tile kt + 1 is issued at the top of tile kt into the buffer tile kt - 1 used (every wave
 // left it before the barrier that ended tile kt - 1); __syncthreads() at the end of the tile is vmcnt(0) + s_barrier
 // (hipcc drains LDS-DMA in front of it), after which the tile is visible to every wave.
-template <int MINW>
+// MSUM: the denominator by the ones-MFMA (16 accumulators, 4 MFMAs per tile) instead of 32 v_add_f32 per tile
+template <int MINW, bool MSUM>
 __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned short* __restrict__ qkv,
                                                                  unsigned short* __restrict__ ctx,
                                                                  float* __restrict__ lse, int T, int H, int q_tiles,
@@ -612,9 +613,9 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
 #pragma unroll
   for (int n = 0; n < 2; ++n) vbase[n] = lds + 2 * TILE_BYTES + v_off(4 * hh + tr_q, 64 * n + tr_colbyte);
 
-  f32x16 ot[2];
+  f32x16 ot[2], lt;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { ot[0][j] = 0.f; ot[1][j] = 0.f; }
+  for (int j = 0; j < 16; ++j) { ot[0][j] = 0.f; ot[1][j] = 0.f; lt[j] = 0.f; }
   bf16x8 ones, mref;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ones[j] = (__bf16)1.0f; mref[j] = (__bf16)0.0f; }
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
       const float dm = m_new - m_run;
       const float alpha = __builtin_amdgcn_exp2f(-dm);
       m_run = m_new;
-      if constexpr (!FIRST) l_run *= alpha;
+      if constexpr (!FIRST && !MSUM) l_run *= alpha;
       mref[0] = hh == 0 ? hi : (__bf16)0.0f;
       mref[1] = hh == 0 ? lo : (__bf16)0.0f;
 #pragma unroll
@@ -674,6 +675,7 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
         if constexpr (!FIRST) {
           ot[0][j] *= alpha;
           ot[1][j] *= alpha;
+          if constexpr (MSUM) lt[j] *= alpha;
         }
         st[0][j] -= dm;
         st[1][j] -= dm;
@@ -685,14 +687,15 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         st[g][j] = __builtin_amdgcn_exp2f(st[g][j]);
-        ps += st[g][j];
+        if constexpr (!MSUM) ps += st[g][j];
       }
-    l_run += ps;
+    if constexpr (!MSUM) l_run += ps;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 pf = cvt8(st[g], 8 * s);
+        if constexpr (MSUM) lt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lt, 0, 0, 0);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
           const unsigned char* vb = vbase[n] + BUF * TILE_BYTES + (32 * g + 16 * s) * 128;
@@ -735,7 +738,9 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
   }
 
   float l_tot;
-  {
+  if constexpr (MSUM) {
+    l_tot = lt[0];
+  } else {
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
@@ -1148,8 +1153,9 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
     if (var >= 4) {
       const long blocks4 = (long)((last_tile_only ? 1 : (T + 127) / 128)) * B * H;
       const int qt4 = last_tile_only ? (T + 127) / 128 - 1 : 0, nq4 = last_tile_only ? 1 : (T + 127) / 128;
-      if (var == 4) hipLaunchKernelGGL(k_attention_dma_bf16<3>, dim3((unsigned)blocks4), dim3(256), 0, s, in, out, lse, T, H, nq4, qt4);
-      else hipLaunchKernelGGL(k_attention_dma_bf16<4>, dim3((unsigned)blocks4), dim3(256), 0, s, in, out, lse, T, H, nq4, qt4);
+      if (var == 4) hipLaunchKernelGGL((k_attention_dma_bf16<3, false>), dim3((unsigned)blocks4), dim3(256), 0, s, in, out, lse, T, H, nq4, qt4);
+      else if (var == 5) hipLaunchKernelGGL((k_attention_dma_bf16<4, false>), dim3((unsigned)blocks4), dim3(256), 0, s, in, out, lse, T, H, nq4, qt4);
+      else hipLaunchKernelGGL((k_attention_dma_bf16<3, true>), dim3((unsigned)blocks4), dim3(256), 0, s, in, out, lse, T, H, nq4, qt4);
       GWW_LAUNCH_CHECK();
       return GWW_OK;
     }

@@ -231,3 +231,68 @@ extern "C" int gww_qscan_interp_f32(const float* energy, long e_total, const int
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Tail of the reference's QTransformAdapter (MLGWSC-1/train.py:146-153, inference.py:345-350), one kernel:
+//     y = AdaptiveAvgPool2d((F, T))(cnn_out);  y = scale * y + bias;  y = y * film_gamma[i] + film_beta[i]
+// cnn_out fp32 [B, Hin, Win] (one channel: the 1x1 convolution's output) -> out fp32 [.., F, T] written straight into
+// the stacked [B, D, F, T] feature tensor (batch stride given; detector i selects the base pointer on the host): the
+// three elementwise passes and torch.stack of the reference shape (4 x 960 KB read + written per window and detector)
+// become one 960 KB write.  HBM-write-bound: 4 F T bytes out per (window, detector), Hin Win 4 bytes in.
+// PyTorch's adaptive pooling regions: rows [floor(f Hin / F), ceil((f + 1) Hin / F)), columns likewise.
+namespace gww {
+namespace {
+constexpr int QT_MAXW = 1024;
+__global__ __launch_bounds__(256) void k_qadapter_tail(const float* __restrict__ y, int Hin, int Win,
+                                                       const float* __restrict__ scale, const float* __restrict__ bias,
+                                                       const float* __restrict__ gamma_i, const float* __restrict__ beta_i,
+                                                       float* __restrict__ out, long out_bstride, int F, int Tn) {
+  __shared__ float rp[QT_MAXW];
+  const int f = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int r0 = (f * Hin) / F, r1 = ((f + 1) * Hin + F - 1) / F;
+  const float* yb = y + (long)b * Hin * Win;
+  for (int c = tid; c < Win; c += 256) {
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += yb[(long)r * Win + c];
+    rp[c] = s;
+  }
+  __syncthreads();
+  const float g = gamma_i[0];
+  const float a = scale[0] * g, c0 = bias[0] * g + beta_i[0];
+  const float inv_r = 1.0f / (float)(r1 - r0);
+  float* orow = out + (long)b * out_bstride + (long)f * Tn;
+  for (int t4 = tid; t4 < Tn / 4; t4 += 256) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int t = 4 * t4 + e;
+      const int k0 = (int)(((long)t * Win) / Tn), k1 = (int)((((long)t + 1) * Win + Tn - 1) / Tn);
+      float s = 0.f;
+      for (int k = k0; k < k1; ++k) s += rp[k];
+      v[e] = fmaf(s * (inv_r / (float)(k1 - k0)), a, c0);
+    }
+    *reinterpret_cast<float4*>(orow + 4 * t4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+}  // namespace
+}  // namespace gww
+
+// y: fp32 [B, Hin, Win]; scale, bias, gamma_i, beta_i: device scalars (gamma_i / beta_i already point at detector i);
+// out: fp32, element (b, f, t) at out[b * out_batch_stride + f * T + t].  T % 4 == 0, Win <= 1024, out 16-byte aligned.
+extern "C" int gww_qadapter_tail_f32(const float* y, int B, int Hin, int Win, const float* scale, const float* bias,
+                                     const float* gamma_i, const float* beta_i, float* out, long out_batch_stride,
+                                     int F, int T, void* stream) {
+  GWW_REQUIRE(y && scale && bias && gamma_i && beta_i && out, "gww_qadapter_tail_f32: NULL argument");
+  GWW_REQUIRE(B >= 0 && Hin > 0 && Win > 0 && Win <= gww::QT_MAXW && F > 0 && F <= 65535 && T > 0 && T % 4 == 0,
+              "gww_qadapter_tail_f32: bad shape B=%d Hin=%d Win=%d F=%d T=%d", B, Hin, Win, F, T);
+  GWW_REQUIRE((((uintptr_t)out) & 15) == 0 && out_batch_stride % 4 == 0, "gww_qadapter_tail_f32: out must be 16-byte aligned");
+  if (B == 0) return GWW_OK;
+  for (int b0 = 0; b0 < B; b0 += 65535) {   // gridDim.y limit
+    const int nb = B - b0 < 65535 ? B - b0 : 65535;
+    hipLaunchKernelGGL(gww::k_qadapter_tail, dim3((unsigned)F, (unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                       y + (long)b0 * Hin * Win, Hin, Win, scale, bias, gamma_i, beta_i, out + (long)b0 * out_batch_stride,
+                       out_batch_stride, F, T);
+  }
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}

@@ -133,14 +133,25 @@ class DeviceSegmentSlicer:
     (``np.add.accumulate`` is the same sequence of float64 additions), once per segment on the host."""
 
     def __init__(self, strain, start_time: float = 0.0, delta_t: float = 1.0 / 2048, step_size: float = 0.1,
-                 peak_offset: float = 0.6, slice_length: int = 2048, key: str = "segment", device="cuda"):
+                 peak_offset: float = 0.6, slice_length: int = 2048, key: str = "segment", device="cuda",
+                 white: bool = True, low_frequency_cutoff=None, segment_duration: float = 0.5,
+                 max_filter_duration: float = 0.25):
         t = torch.as_tensor(np.asarray(strain) if not torch.is_tensor(strain) else strain)
         if t.dim() != 2:
             raise ValueError("strain must be [detectors, samples]")
-        self.dss = t.to(device=device, dtype=torch.float32).contiguous()       # the ONE host-to-device copy
         self.key = key
         self.start_time = start_time
         self.delta_t = 1.0 / (1.0 / delta_t)          # the reference's double inversion (:196), kept bit for bit
+        if white:
+            self.dss = t.to(device=device, dtype=torch.float32).contiguous()   # the ONE host-to-device copy
+        else:
+            # SegmentSlicer.process (:218-246): whiten every detector on the device (whiten.py) and move the start time
+            # by the corrupted edge (the reference adds a flat 0.125 s)
+            from .whiten import whiten
+            self.dss = whiten(t.to(device), delta_t=self.delta_t, low_frequency_cutoff=low_frequency_cutoff,
+                              segment_duration=segment_duration, max_filter_duration=max_filter_duration,
+                              device=device).contiguous()
+            self.start_time = self.start_time + 0.125
         self.step_size = step_size
         self.peak_offset = peak_offset
         self.slice_length = slice_length

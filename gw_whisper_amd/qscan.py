@@ -9,9 +9,10 @@ written) and is checked only against the independent CPU restatement ``oracle/qs
 ``QScan(duration, sample_rate, spectrogram_shape, qrange)(x [B, N])`` -> ``[B, F, T]``: forward-normalised real DFT
 (one fp32 MFMA GEMM against a cached DFT matrix), windowed tile energies + median normalisation per (Q plane,
 frequency row), the plane with the largest energy over the whole batch, bicubic resampling.  ``QTransformAdapter``
-is the reference's module with the same parameter names: Q-scan (no grad) -> small CNN -> adaptive pool to
-(80, 3000) -> global and per-detector affine; the CNN is plain ``torch.nn`` (0.3 GFLOP per sample, 1 % of the
-encoder) and trains through the frozen encoder via the encoder's input gradient.
+is the reference's module with the same parameter names: Q-scan (no grad) -> small CNN (plain ``torch.nn``, 0.3 GFLOP
+per sample, 1 % of the encoder) -> adaptive pool to (80, 3000) + global and per-detector affine + the stack over
+detectors as ONE HIP kernel (``gww_qadapter_tail_f32``); it trains through the frozen encoder via the encoder's input
+gradient.
 """
 
 from __future__ import annotations
@@ -155,6 +156,47 @@ class QScan(nn.Module):
         return out.reshape(*lead, F, T)
 
 
+class _AdapterTail(torch.autograd.Function):
+    """pool -> global affine -> FiLM of one detector as ONE HIP kernel that writes into the stacked feature tensor
+    (``gww_qadapter_tail_f32``).  Backward (the adapter trains through the frozen encoder, MLGWSC-1/train.py:494-504):
+    PyTorch's own adaptive-pool backward on the incoming gradient plus four scalar reductions -- training-side only,
+    the inference path never runs it."""
+
+    @staticmethod
+    def forward(ctx, y, scale, bias, gamma, beta, out, det):
+        B, Hin, Win = y.shape
+        F, T = out.shape[-2:]
+        yc = y.detach().to(torch.float32).contiguous()
+        view = out[:, det]
+        with torch.cuda.device(y.device):
+            check(lib().gww_qadapter_tail_f32(yc.data_ptr(), B, Hin, Win, scale.data_ptr(), bias.data_ptr(),
+                                              gamma[det:det + 1].data_ptr(), beta[det:det + 1].data_ptr(),
+                                              view.data_ptr(), out.stride(0), F, T,
+                                              torch.cuda.current_stream().cuda_stream), "gww_qadapter_tail_f32")
+        ctx.save_for_backward(yc, scale, bias, gamma)
+        ctx.det, ctx.shape = det, (F, T)
+        ctx.mark_dirty(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        y, scale, bias, gamma = ctx.saved_tensors
+        det = ctx.det
+        g = g_out[:, det].to(torch.float32)                                   # [B, F, T]
+        p = torch.nn.functional.adaptive_avg_pool2d(y[:, None], ctx.shape)[:, 0]
+        gam = gamma[det]
+        d_scale = (g * p).sum().reshape(1) * gam
+        d_bias = g.sum().reshape(1) * gam
+        d_gamma = torch.zeros_like(gamma)
+        d_gamma[det] = (g * (scale * p + bias)).sum()
+        d_beta = torch.zeros_like(gamma)
+        d_beta[det] = g.sum()
+        d_y = torch.ops.aten._adaptive_avg_pool2d_backward((g * (scale * gam))[:, None].contiguous(), y[:, None])[:, 0]
+        g_rest = g_out.clone()
+        g_rest[:, det] = 0                                                    # this call overwrote detector `det` of `out`
+        return d_y, d_scale, d_bias, d_gamma, d_beta, g_rest, None
+
+
 class QTransformAdapter(nn.Module):
     """The reference's Q-transform adapter, both variants, same constructor arguments, parameter names and forward:
 
@@ -212,13 +254,14 @@ class QTransformAdapter(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, D, _ = x.shape
-        outs = []
+        F, T = self.target_shape
+        if T % 4 != 0:
+            raise _lib.GwwError("QTransformAdapter: target_shape[1] must be a multiple of 4")
+        out = torch.empty((B, D, F, T), dtype=torch.float32, device=x.device)
         for i in range(D):
             with torch.no_grad():
                 qspec = self.q_transform(x[:, i]).unsqueeze(1)        # [B, 1, F, T]  (plane chosen per call, per detector)
-            y = self.freq_adapter(qspec)
-            y = self.final_pool(y).squeeze(1)
-            y = self.scale * y + self.bias
-            y = y * self.film_gamma[i] + self.film_beta[i]
-            outs.append(y)
-        return torch.stack(outs, dim=1)
+            y = self.freq_adapter(qspec).squeeze(1)                   # small CNN (torch.nn): [B, F', T']
+            # final_pool + scale / bias + FiLM and the stack over detectors: one kernel, one 960 KB write per window
+            out = _AdapterTail.apply(y, self.scale, self.bias, self.film_gamma, self.film_beta, out, i)
+        return out

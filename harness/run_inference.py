@@ -9,8 +9,8 @@ Same positional arguments and flags as the reference (``inputfile outputfile --w
 --debug-triggers-file``), same output datasets (``time``, ``stat``, ``var``, ``all_vals``).  Differences, all forced by
 the offline box:
 
-  * ``--white`` is required: whitening is PyCBC (``inference.py:56-137``) and not part of this build (DESIGN.md
-    section 6) -- the input must already be whitened, as the reference's ``--white`` mode expects;
+  * without ``--white`` every segment is whitened on the device first (``gw_whisper_amd/whiten.py``, the counterpart of
+    the reference's PyCBC whitening ``inference.py:56-137``; parity unpinned, PyCBC is absent -- DESIGN.md section 6);
   * files are HDF5 with the reference's layout (``/<detector>/<segment key>`` datasets with ``start_time`` and
     ``delta_t`` attributes) when ``h5py`` is importable, otherwise ``.npz`` with ``<detector>/<key>`` arrays plus
     ``<key>/start_time`` and ``<key>/delta_t`` scalars; the output follows the input's kind;
@@ -44,7 +44,7 @@ def parse_args(argv=None):
     p.add_argument("--force", action="store_true", help="Overwrite existing output file.")
     p.add_argument("inputfile", type=str, help="Input HDF5 / .npz (ignored with --synthetic).")
     p.add_argument("outputfile", type=str, help="Output HDF5 / .npz (must not exist unless --force).")
-    p.add_argument("--white", action="store_true", help="Input is already whitened (required here).")
+    p.add_argument("--white", action="store_true", help="Input is already whitened (otherwise every segment is whitened on the device first).")
     p.add_argument("--softmax", action="store_true", help="Use Softmax outputs (default is USR logits).")
     p.add_argument("--coinc-window", type=float, default=0.1, help="(Reserved) coincidence window; not used.")
     p.add_argument("--lora-weights", type=str, default=None, help="peft adapter directory.")
@@ -158,8 +158,10 @@ def get_triggers(args, device, rank, world):
     triggers, all_vals = {}, []
     for key in sorted(segs, key=lambda k: segs[k][0].shape[1], reverse=True):
         strain, start, dt = segs[key]
+        # --white: the file already holds whitened strain; otherwise every segment is whitened on the device first
+        # (inference.py:218-246 -> gw_whisper_amd/whiten.py, parity unpinned: PyCBC is absent)
         slicer = inf.DeviceSegmentSlicer(strain, start_time=start, delta_t=dt, step_size=args.step_size, key=key,
-                                         device=device)
+                                         device=device, white=args.white)
         w0, w1 = inf.shard_windows(len(slicer), rank, world, args.batch_size)
         logging.info("rank %d: segment %s, windows [%d, %d) of %d", rank, key, w0, w1, len(slicer))
         trig, vals = inf.evaluate_slices(slicer, network, trigger_threshold=args.trigger_threshold,
@@ -180,9 +182,6 @@ def main(argv=None) -> int:
     args = parse_args(argv)
     logging.basicConfig(level=logging.DEBUG if args.debug else (logging.INFO if args.verbose else logging.WARN),
                         format="%(levelname)s | %(asctime)s: %(message)s", datefmt="%d.%m.%Y %H:%M:%S")
-    if not args.white:
-        raise SystemExit("run_inference: --white is required -- whitening (PyCBC, inference.py:56-137) is not part of "
-                         "this build; whiten the strain first (DESIGN.md section 6).")
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if os.path.isfile(args.outputfile) and not args.force:
         raise RuntimeError("Output file exists. Use --force to overwrite.")

@@ -260,6 +260,25 @@ int gww_qscan_energy_f32(const float* fseries, int ld, int B, const int* rows, c
  * row count.  chosen (optional): device int receiving the selected plane. */
 int gww_qscan_interp_f32(const float* energy, long e_total, const int* rows, const int* plane_rows, int n_planes,
                          const unsigned int* plane_max, int B, int F, int T, float* out, int* chosen, void* stream);
+/* Tail of the reference's QTransformAdapter (MLGWSC-1/train.py:146-153, inference.py:345-350) as ONE kernel:
+ * AdaptiveAvgPool2d((F, T)) of the adapter CNN's output y fp32 [B, Hin, Win], then scale * y + bias, then
+ * * film_gamma[i] + film_beta[i]; the result goes straight into the stacked [B, D, F, T] feature tensor: element
+ * (b, f, t) at out[b * out_batch_stride + f * T + t] (the caller offsets `out` to detector i).  scale / bias / gamma_i /
+ * beta_i are device scalars (no host sync).  T % 4 == 0, Win <= 1024. */
+int gww_qadapter_tail_f32(const float* y, int B, int Hin, int Win, const float* scale, const float* bias,
+                          const float* gamma_i, const float* beta_i, float* out, long out_batch_stride, int F, int T,
+                          void* stream);
+/* Whitening of the search pipeline's strain (MLGWSC-1/inference.py:56-137 -> PyCBC 2.4.0 TimeSeries.psd / welch /
+ * inverse_spectrum_truncation; PARITY UNPINNED -- PyCBC is not installed, the kernels follow oracle/whiten.py).
+ * gww_welch_power_f32: |rDFT|^2 * scale of the windowed Welch segments from their (re, im) rows (a gww_gemm_f32 against
+ * the windowed real-DFT matrix), DC / Nyquist halved.  gww_column_median_f32: numpy.median over the segments per
+ * frequency bin (values >= 0).  gww_fir_f32: the inverse-spectrum-truncated whitening filter applied as a FIR in the
+ * time domain, out[d][n] = sum_u g[d][u] xp[d][n + u] (xp circularly padded by the caller, taps zero-padded to a
+ * multiple of 4). */
+int gww_welch_power_f32(const float* spec, long ld, long n_seg, int n_bins, float scale, float* power, void* stream);
+int gww_column_median_f32(const float* power, long n_seg, int n_bins, float* median, void* stream);
+int gww_fir_f32(const float* xp, long xp_stride, const float* g, int taps4, int D, float* out, long out_stride,
+                long n_out, void* stream);
 int gww_gemm_f32(const float* A, const float* W, const float* bias, const float* resid, float* C,
                  long M, int N, int K, int epilogue, void* stream);
 /* softmax(q k^T) v per head, q pre-scaled; qkv [B,T,3*d] (q|k|v), ctx [B,T,d]; head_dim 64 */

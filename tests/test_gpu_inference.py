@@ -106,7 +106,7 @@ def test_sharded_window_ranges_reproduce_the_full_evaluation(T, gww):
 def test_run_inference_harness_end_to_end(T, gww, tmp_path):
     """harness/run_inference.py (counterpart of MLGWSC-1/inference.py main): .npz segments in the reference's layout
     -> Q-adapter -> DoRA-wrapped whisper-tiny -> scores -> clustered triggers, equal to the same pipeline assembled by
-    hand; --white is mandatory and an existing output needs --force."""
+    hand; an existing output needs --force."""
     import importlib.util
     from gw_whisper_amd import inference as inf
     import os
@@ -124,8 +124,6 @@ def test_run_inference_harness_end_to_end(T, gww, tmp_path):
     src, dst = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
     np.savez(src, **arrays)
     argv = [src, dst, "--white", "--trigger-threshold=-1e9", "--batch-size", "4", "--debug-triggers-file", str(tmp_path / "trig.npz")]
-    with pytest.raises(SystemExit):
-        ri.main([src, dst])                                   # no --white
     assert ri.main(argv) == 0
     with pytest.raises(RuntimeError):
         ri.main(argv)                                         # exists, no --force
@@ -210,3 +208,51 @@ def test_config5_small_q_adapter_search_matches_oracle_pipeline(T, gww):
     err = np.abs(scores - ref).max()
     print(f"config 5 (whisper-small + Q-adapter 512x512): scores {scores.round(4)} oracle {ref.round(4)} max err {err:.3e}")
     assert err < 5e-3
+
+
+def _colored_strain(n, seed, scale=1e-21):
+    """Gaussian noise with a LIGO-like coloured spectrum (steep low-frequency wall, a line) at raw-strain amplitude."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(n)
+    f = np.fft.rfftfreq(n, 1 / 2048)
+    shape = 1 / (1 + (f / 60) ** 2) + 40.0 / (1 + (f / 8) ** 3) + 0.03 + 5.0 * np.exp(-((f - 300) / 0.7) ** 2)
+    return np.fft.irfft(np.fft.rfft(x) * shape, n) * scale
+
+
+@pytest.mark.parametrize("n,cutoff", [(2048 * 32, None), (2048 * 64 + 640, None), (2048 * 48, 15.0)])
+def test_whiten_matches_the_pycbc_restatement(T, gww, n, cutoff):
+    """gw_whisper_amd.whiten (Welch-median PSD by fp32-MFMA DFT + radix-select median, PyCBC's inverse-spectrum
+    truncation, FIR in the time domain) against oracle/whiten.py, the fp64 restatement of the PyCBC 2.4.0 routines
+    the reference calls (MLGWSC-1/inference.py:56-137).  PARITY UNPINNED with respect to PyCBC itself (absent).
+    Whitened noise has standard deviation sqrt(fs / 2) = 32; tolerance 2e-3 of that on every sample."""
+    from gw_whisper_amd.whiten import whiten, welch_median_psd
+    from oracle import whiten as ow
+    x = np.stack([_colored_strain(n, 5), _colored_strain(n, 6, scale=3e-22)])
+    ref, psd_ref = ow.whiten(x, low_frequency_cutoff=cutoff, return_psd=True)
+    got, psd = whiten(x, low_frequency_cutoff=cutoff, return_psd=True)
+    assert got.shape == ref.shape == (2, n - 512) and got.dtype == T.float32
+    p = psd.cpu().numpy()
+    np.testing.assert_allclose(p, np.stack(psd_ref), rtol=2e-4)          # fp32 DFT + exact median against fp64
+    g = got.double().cpu().numpy()
+    err = np.abs(g - ref).max()
+    print(f"whiten n={n} cutoff={cutoff}: std {g.std():.3f} (reference {ref.std():.3f}), max |err| {err:.3e}")
+    assert 20 < ref.std() < 40
+    assert err < 2e-3 * 32
+    one = whiten(x[0], low_frequency_cutoff=cutoff)
+    assert one.shape == (n - 512,) and T.equal(one, got[0])
+
+
+def test_slicer_whitens_raw_strain_like_the_reference_process(T, gww):
+    """SegmentSlicer.process without --white (MLGWSC-1/inference.py:218-246): whiten every detector, start time + 0.125 s,
+    windows cut from the whitened series."""
+    from gw_whisper_amd import inference as inf
+    from oracle import whiten as ow
+    n = 2048 * 20
+    x = np.stack([_colored_strain(n, 1), _colored_strain(n, 2)])
+    sl = inf.DeviceSegmentSlicer(x, start_time=1000.0, white=False)
+    ref = ow.whiten(x)
+    assert sl.start_time == 1000.125 and sl.dss.shape == (2, n - 512)
+    assert len(sl) == 1 + (n - 512 - 2048) // 204
+    w = sl.windows(3, 5).cpu().numpy()
+    np.testing.assert_allclose(w[1], ref[:, 4 * 204:4 * 204 + 2048], atol=2e-3 * 32)
+    assert sl.times_host(0, 1)[0] == 1000.125 + 0.6

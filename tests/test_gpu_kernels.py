@@ -285,7 +285,7 @@ def _attn_ref_log2q(qkv_l2, H):
     return o.transpose(0, 2, 1, 3).reshape(B, Tn, d)
 
 
-@pytest.fixture(params=["l2", "l2_var0", "l2_var1", "l2_var3", "l2_var4", "l2_var5", "l2_8waves"])
+@pytest.fixture(params=["l2", "l2_var0", "l2_var1", "l2_var3", "l2_var4", "l2_var5", "l2_var6", "l2_8waves"])
 def att_variant(request, monkeypatch):
     """k_attention_l2_bf16 (the inference path's kernel) and its tuning variants; the launcher reads GWW_ATT_VAR /
     GWW_ATT_WAVES per call."""

@@ -88,3 +88,31 @@ def test_q_adapter_feeds_the_encoder_and_trains_through_it(T, gww):
     for n, p in model.adapter.named_parameters():
         assert p.grad is not None and T.isfinite(p.grad).all(), n
     assert model.adapter.film_gamma.grad.abs().max() > 0 and model.adapter.freq_adapter[0].weight.grad.abs().max() > 0
+
+
+@pytest.mark.parametrize("Hin,Win", [(32, 32), (128, 128), (80, 3000), (33, 50)])
+def test_adapter_tail_kernel_matches_the_torch_composition(T, gww, Hin, Win):
+    """gww_qadapter_tail_f32 (pool -> scale / bias -> FiLM -> stack, one kernel) against the reference's own sequence of
+    torch ops (MLGWSC-1/train.py:146-153): forward to 1e-6, and the gradients of y, scale, bias, film_gamma, film_beta.
+    32 x 32 is what the train.py CNN hands over (128 x 128 Q-scan, two MaxPool2d(2)), 128 x 128 the inference.py one."""
+    from gw_whisper_amd.qscan import _AdapterTail
+    T.manual_seed(Hin * 1000 + Win)
+    B, D = 3, 2
+    ys = [T.randn(B, Hin, Win, device="cuda", requires_grad=True) for _ in range(D)]
+    scale = T.tensor([0.7], device="cuda", requires_grad=True)
+    bias = T.tensor([-0.2], device="cuda", requires_grad=True)
+    gamma = T.tensor([1.3, 0.8], device="cuda", requires_grad=True)
+    beta = T.tensor([0.05, -0.1], device="cuda", requires_grad=True)
+    out = T.empty((B, D, 80, 3000), device="cuda")
+    for i in range(D):
+        out = _AdapterTail.apply(ys[i], scale, bias, gamma, beta, out, i)
+    ref = T.stack([(scale * T.nn.functional.adaptive_avg_pool2d(ys[i][:, None], (80, 3000))[:, 0] + bias) * gamma[i] + beta[i]
+                   for i in range(D)], dim=1)
+    assert out.shape == ref.shape == (B, D, 80, 3000)
+    assert (out - ref).abs().max().item() < 2e-6
+    w = T.randn_like(ref)
+    leaves = ys + [scale, bias, gamma, beta]
+    g_hip = T.autograd.grad((out * w).sum(), leaves)
+    g_ref = T.autograd.grad((ref * w).sum(), leaves)
+    for a, b in zip(g_hip, g_ref):
+        assert (a - b).abs().max().item() < 2e-3 * (b.abs().max().item() + 1e-6), (a.shape, (a - b).abs().max().item())
