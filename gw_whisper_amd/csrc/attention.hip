@@ -538,7 +538,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void k_attention_l2_bf16(
 // left it before the barrier that ended tile kt - 1); __syncthreads() at the end of the tile is vmcnt(0) + s_barrier
 // (hipcc drains LDS-DMA in front of it), after which the tile is visible to every wave.
 // MSUM: the denominator by the ones-MFMA (16 accumulators, 4 MFMAs per tile) instead of 32 v_add_f32 per tile
-template <int MINW, bool MSUM>
+// NOMAX: no row maximum in the steady state.  The tile's probabilities are exponentiated against the current reference
+// straight away and their row sum (needed anyway) is the overflow detector: any p above 2^kDefer -- or an inf -- makes
+// the sum exceed the trigger; only then (rare, wave-uniform) the scores are recomputed from the K tile still in LDS,
+// the exact row maximum is taken and O, l and the reference are re-based.  23 v_max per tile leave the hot path.
+template <int MINW, bool MSUM, bool NOMAX>
 __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned short* __restrict__ qkv,
                                                                  unsigned short* __restrict__ ctx,
                                                                  float* __restrict__ lse, int T, int H, int q_tiles,
@@ -628,67 +632,86 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
     constexpr bool FIRST = decltype(first_c)::value, MASKED = decltype(masked_c)::value;
     if (kt + 1 < n_kt) dma(kt + 1, std::integral_constant<int, BUF ^ 1>{});
     f32x16 st[2];
+    auto scores = [&]() {
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      f32x16 z;
+      for (int g = 0; g < 2; ++g) {
+        f32x16 z;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) z[j] = 0.f;
-      if constexpr (FIRST) st[g] = z;
-      else st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, mref, z, 0, 0, 0);
+        for (int j = 0; j < 16; ++j) z[j] = 0.f;
+        if constexpr (FIRST) st[g] = z;
+        else st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, mref, z, 0, 0, 0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase[s] + BUF * TILE_BYTES + g * (32 * 128));
-        st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[g], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase[s] + BUF * TILE_BYTES + g * (32 * 128));
+          st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[g], 0, 0, 0);
+        }
       }
-    }
-    if constexpr (MASKED) {
+      if constexpr (MASKED) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int key = kt * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
+            if (key >= T) st[g][j] = -INFINITY;
+          }
+      }
+    };
+    // exact row maximum of the tile (both key halves), then move the reference of the rows that need it
+    auto rebase = [&]() {
+      float tmax = st[0][0];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tmax = fmaxf(tmax, st[g][j]);
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+      if (FIRST || NOMAX || __builtin_amdgcn_ballot_w64(tmax > kDeferL2) != 0) {
+        const float want = m_run + (FIRST ? tmax : fmaxf(tmax, 0.f));
+        const __bf16 hi = (__bf16)(-want);
+        const __bf16 lo = (__bf16)(-want - (float)hi);
+        const float m_new = -((float)hi + (float)lo);
+        const float dm = m_new - m_run;
+        const float alpha = __builtin_amdgcn_exp2f(-dm);
+        m_run = m_new;
+        if constexpr (!FIRST && !MSUM) l_run *= alpha;
+        mref[0] = hh == 0 ? hi : (__bf16)0.0f;
+        mref[1] = hh == 0 ? lo : (__bf16)0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          if constexpr (!FIRST) {
+            ot[0][j] *= alpha;
+            ot[1][j] *= alpha;
+            if constexpr (MSUM) lt[j] *= alpha;
+          }
+          st[0][j] -= dm;
+          st[1][j] -= dm;
+        }
+      }
+    };
+    scores();
+    if constexpr (FIRST || !NOMAX) rebase();
+    float ps = 0.f;
+    auto exps = [&]() {
+      ps = 0.f;
 #pragma unroll
       for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          const int key = kt * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
-          if (key >= T) st[g][j] = -INFINITY;
+          st[g][j] = __builtin_amdgcn_exp2f(st[g][j]);
+          if constexpr (!MSUM || NOMAX) ps += st[g][j];
         }
-    }
-    float tmax = st[0][0];
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) tmax = fmaxf(tmax, st[g][j]);
-    {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
-      tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    if (FIRST || __builtin_amdgcn_ballot_w64(tmax > kDeferL2) != 0) {
-      const float want = m_run + (FIRST ? tmax : fmaxf(tmax, 0.f));
-      const __bf16 hi = (__bf16)(-want);
-      const __bf16 lo = (__bf16)(-want - (float)hi);
-      const float m_new = -((float)hi + (float)lo);
-      const float dm = m_new - m_run;
-      const float alpha = __builtin_amdgcn_exp2f(-dm);
-      m_run = m_new;
-      if constexpr (!FIRST && !MSUM) l_run *= alpha;
-      mref[0] = hh == 0 ? hi : (__bf16)0.0f;
-      mref[1] = hh == 0 ? lo : (__bf16)0.0f;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if constexpr (!FIRST) {
-          ot[0][j] *= alpha;
-          ot[1][j] *= alpha;
-          if constexpr (MSUM) lt[j] *= alpha;
-        }
-        st[0][j] -= dm;
-        st[1][j] -= dm;
+    };
+    exps();
+    if constexpr (NOMAX && !FIRST) {
+      // 2^kDeferL2 = e^8 = 2981: one probability above it, or an inf, lifts the half-row sum over the trigger
+      if (__builtin_amdgcn_ballot_w64(!(ps <= 2981.0f)) != 0) {   // wave-uniform, rare
+        scores();
+        rebase();
+        exps();
       }
     }
-    float ps = 0.f;
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        st[g][j] = __builtin_amdgcn_exp2f(st[g][j]);
-        if constexpr (!MSUM) ps += st[g][j];
-      }
     if constexpr (!MSUM) l_run += ps;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -761,368 +784,18 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Software-pipelined form of the same kernel (experimental: GWW_ATT_PIPE=1 makes the encoder use it).
-// The kernel above runs S = K Q^T, the softmax VALU and the P V product of ONE tile back to back, so inside a wave
-// the matrix pipe idles through the 32 v_exp / 16 cvt / 20 max of every tile and the VALU idles through the MFMAs
-// (stamps: ~1600 cycles per wave-tile against ~650 of MFMA).  Here one straight-line block per tile holds the
-// S MFMAs of tile j+1, the exponentials of tile j and the P V MFMAs of tile j, so the scheduler can put the VALU
-// work into the MFMA shadows of the SAME wave:
-//   * scores live in log2 units relative to the running reference m: the caller folds log2(e) into the q
-//     projection (encoder.hip packs the LN-folded q panel with log2(e) / 8; scaling the bf16 q here would add a
-//     second rounding), and -m enters through the C operand of the first k-step (`cneg`), so p = v_exp_f32(s)
-//     with no multiply-add per score;
-//   * the row maximum of tile j+1 is reduced inside the block too; the (rare, deferred by kDeferLog2) re-basing
-//     of O, l and the already computed scores happens between blocks;
-//   * K runs one tile ahead of V through the same two LDS buffers each (K(j+2) and V(j+1) are staged at the end
-//     of block j); still one barrier per tile.  The tile loop is unrolled by two so the score registers swap
-//     roles without copies and every LDS address is an immediate.
-// MB = 32-row query blocks per wave.  MB = 2 (GWW_ATT_MB=2; 64 rows per wave, one wave per SIMD with the whole
-// register file): one set of K / V fragment reads, waits, addresses and loop overhead feeds twice the MFMAs and
-// exponentials (the kernel above issues ~225 instructions per 20 MFMAs).  Measured: correct, but 1.87 ms per
-// whisper-tiny layer -- with a single wave per SIMD every LDS wait and barrier of the compiler's schedule is
-// exposed (130 cycles per MFMA).  MB = 1 (two waves per SIMD): 1.20 ms; the plain kernel (three waves): 1.13 ms.
-template <int NW, int MB>
-__global__ __launch_bounds__(NW * 64, MB == 1 ? 2 : 1) void k_attention_pipe_bf16(const unsigned short* __restrict__ qkv,
-                                                                               unsigned short* __restrict__ ctx,
-                                                                               float* __restrict__ lse, int T, int H,
-                                                                               int q_tiles, int qt0) {
-  static_assert(NW == 4 && (MB == 1 || MB == 2), "4 waves x MB x 32 query rows per workgroup");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KB * DH * 2];   // 32 KB
-  constexpr int TILE_BYTES = KB * DH * 2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned nblk = gridDim.x, per = nblk >> 3;
-  const unsigned wid = blockIdx.x < 8 * per ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
-  const int qt = qt0 + wid % q_tiles;
-  const int bh = wid / q_tiles;
-  const int b = bh / H, h = bh - b * H;
-  const int d = H * DH;
-  const long row_stride = 3L * d;
-  const unsigned short* base = qkv + (long)b * T * row_stride;
-  const unsigned short* qp = base + h * DH;
-  const unsigned short* kp = base + d + h * DH;
-  const unsigned short* vp = base + 2 * d + h * DH;
-  const int r = lane & 31, hh = lane >> 5;
-  int q_row[MB];
-  // Q fragments (B operand of K Q^T); q arrives in log2 units (log2(e) / 8 folded into the packed q_proj panel)
-  bf16x8 qf[MB][4];
-#pragma unroll
-  for (int m = 0; m < MB; ++m) {
-    q_row[m] = qt * (NW * 32 * MB) + wave * (32 * MB) + 32 * m + r;
-    const int q_ld = q_row[m] < T ? q_row[m] : T - 1;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      qf[m][s] = *reinterpret_cast<const bf16x8*>(qp + (long)q_ld * row_stride + 16 * s + 8 * hh);
-  }
-
-  constexpr int NCH = 512 / (NW * 64);
-  int st_row[NCH], st_chunk[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = tid + NW * 64 * i;
-    st_row[i] = c >> 3;
-    st_chunk[i] = c & 7;
-  }
-  u32x4 rk[NCH], rv[NCH];
-  // global addresses = wave-uniform tile base (scalar registers) + a 32-bit per-lane offset that never changes;
-  // only the ragged last tile clamps its rows to T - 1, through a second set of offsets
-  const int n_kt = (T + KB - 1) / KB;
-  unsigned off_full[NCH], off_last[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    off_full[i] = (unsigned)(st_row[i] * (int)row_stride + st_chunk[i] * 8);
-    int key = (n_kt - 1) * KB + st_row[i];
-    if (key >= T) key = T - 1;
-    off_last[i] = (unsigned)((key - (n_kt - 1) * KB) * (int)row_stride + st_chunk[i] * 8);
-  }
-  auto gload_k = [&](int kt) {
-    const unsigned short* kb = kp + (long)kt * KB * row_stride;
-    const bool last = kt == n_kt - 1;   // wave-uniform
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) rk[i] = *reinterpret_cast<const u32x4*>(kb + (last ? off_last[i] : off_full[i]));
-  };
-  auto gload_v = [&](int kt) {
-    const unsigned short* vb = vp + (long)kt * KB * row_stride;
-    const bool last = kt == n_kt - 1;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) rv[i] = *reinterpret_cast<const u32x4*>(vb + (last ? off_last[i] : off_full[i]));
-  };
-  auto lstore_k = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(lds + buf * TILE_BYTES + k_off(st_row[i], st_chunk[i])) = rk[i];
-  };
-  auto lstore_v = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-      *reinterpret_cast<u32x4*>(lds + (2 + buf) * TILE_BYTES + v_off(st_row[i], st_chunk[i] * 16)) = rv[i];
-  };
-
-  f32x16 ot[MB][2], lt[MB], cneg[MB];
-  float m_run[MB], tmax[MB];   // log2 units
-#pragma unroll
-  for (int m = 0; m < MB; ++m) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { ot[m][0][j] = 0.f; ot[m][1][j] = 0.f; lt[m][j] = 0.f; cneg[m][j] = 0.f; }
-    m_run[m] = 0.f;
-  }
-  bf16x8 ones;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
-  const int tr_colbyte = (((lane & 31) >> 4) * 16 + 4 * tr_p) * 2;
-  const bool ragged = (T % KB) != 0;
-  constexpr float kDeferLog2 = 8.0f * kLog2e;
-  typedef f32x16 Scores[MB][2];   // [row block][32-key half]: reg <-> key 32 g + (reg&3) + 8 (reg>>2) + 4 hh
-
-  auto mask_last = [&](Scores& st) {   // keys >= T of the last tile
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int key = (n_kt - 1) * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
-          if (key >= T) st[m][g][j] = -INFINITY;
-        }
-  };
-  // move the reference of row block m by dm (per row): O, l and the scores already computed against the old one
-  auto rebase = [&](Scores& st, int m, float dm) {
-    const float alpha = __builtin_amdgcn_exp2f(-dm);
-    m_run[m] += dm;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      lt[m][j] *= alpha;
-      ot[m][0][j] *= alpha;
-      ot[m][1][j] *= alpha;
-      st[m][0][j] -= dm;
-      st[m][1][j] -= dm;
-      cneg[m][j] = -m_run[m];
-    }
-  };
-  // one tile: [S of the next tile] + exp of this tile + P V of this tile (+ row max of the next tile)
-  auto block = [&](Scores& sc, Scores& sn, auto par_c, auto next_c, auto mask_c) {
-    constexpr int PAR = decltype(par_c)::value;            // tile parity: V buffer PAR, next K buffer PAR ^ 1
-    constexpr bool NEXT = decltype(next_c)::value, MASK = decltype(mask_c)::value;
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-      if (__builtin_amdgcn_ballot_w64(tmax[m] > kDeferLog2) != 0) rebase(sc, m, fmaxf(tmax[m], 0.f));   // rare
-    // Phase 1: all K fragments of the next tile are requested first, then its S MFMAs (the 32-key halves and the
-    // row blocks alternate, so no MFMA waits for its predecessor's accumulator) carry 4 of this tile's
-    // exponentials each.  Phase 2: 4 x (P -> bf16, 3 MFMAs per row block) with the second half's V fragments
-    // requested two steps ahead and the row maximum of the next tile's scores in the MFMA shadows.
-    typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
-    const unsigned char* vs = lds + (2 + PAR) * TILE_BYTES;
-    bf16x8 vfr[4][2];
-    auto load_v = [&](int c) {   // V^T A operands of step c = (g, s): keys 32 g + 16 s + ..., dh = 32 n + r
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const int key0 = 16 * c + 4 * hh + tr_q;
-        const int cb = 64 * n + tr_colbyte;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vs + v_off(key0, cb)));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vs + v_off(key0 + 8, cb)));
-        bf16x8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-        vfr[c][n] = vf;
-      }
-    };
-    if constexpr (NEXT) {
-      bf16x8 kf[2][4];
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          kf[g][s] = *reinterpret_cast<const bf16x8*>(lds + (PAR ^ 1) * TILE_BYTES + k_off(32 * g + r, 2 * s + hh));
-      load_v(0);
-      load_v(1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-          for (int m = 0; m < MB; ++m) {
-            sn[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[g][s], qf[m][s], s == 0 ? cneg[m] : sn[m][g], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int idx = 4 * (2 * s + g) + j;
-              sc[m][idx >> 4][idx & 15] = __builtin_amdgcn_exp2f(sc[m][idx >> 4][idx & 15]);
-            }
-          }
-      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // 8 K + 8 V fragment reads (steps 0 and 1 of phase 2)
-#pragma unroll
-      for (int i = 0; i < 8 * MB; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);   // 4 v_exp_f32
-      }
-    } else {
-      load_v(0);
-      load_v(1);
-#pragma unroll
-      for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-          for (int j = 0; j < 16; ++j) sc[m][g][j] = __builtin_amdgcn_exp2f(sc[m][g][j]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    load_v(2);   // the second half's V fragments: two steps ahead of their use
-    load_v(3);
-    float t[MB];
-#pragma unroll
-    for (int m = 0; m < MB; ++m) t[m] = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int g = c >> 1, s2 = c & 1;
-#pragma unroll
-      for (int m = 0; m < MB; ++m) {
-        const bf16x8 pf = cvt8(sc[m][g], 8 * s2);
-        lt[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lt[m], 0, 0, 0);
-        ot[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[c][0], pf, ot[m][0], 0, 0, 0);
-        ot[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[c][1], pf, ot[m][1], 0, 0, 0);
-        if constexpr (NEXT) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int reg = 8 * s2 + j;
-            if constexpr (MASK) {
-              const int key = (n_kt - 1) * KB + 32 * g + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-              if (key >= T) sn[m][g][reg] = -INFINITY;
-            }
-            t[m] = fmaxf(t[m], sn[m][g][reg]);
-          }
-        }
-      }
-      if constexpr (!MASK) {
-        if (c == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // V fragments of steps 2 and 3
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);               // 4 cvt_pk
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);               // row maximum of the next tile
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (NEXT) {
-#pragma unroll
-      for (int m = 0; m < MB; ++m) tmax[m] = fmaxf(t[m], __shfl_xor(t[m], 32, 64));
-    }
-  };
-  using P0 = std::integral_constant<int, 0>;
-  using P1 = std::integral_constant<int, 1>;
-  using Yes = std::true_type;
-  using No = std::false_type;
-
-  // ---- prologue: S(0) against reference 0, then the reference becomes the row maximum of tile 0
-  Scores sa, sb;
-  gload_k(0);
-  lstore_k(0);
-  if (n_kt > 1) gload_k(1);
-  gload_v(0);
-  __syncthreads();
-#pragma unroll
-  for (int m = 0; m < MB; ++m)
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(lds + k_off(32 * g + r, 2 * s + hh));
-        sa[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[m][s], s == 0 ? cneg[m] : sa[m][g], 0, 0, 0);
-      }
-  if (n_kt == 1 && ragged) mask_last(sa);
-#pragma unroll
-  for (int m = 0; m < MB; ++m) {
-    float t = sa[m][0][0];
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) t = fmaxf(t, sa[m][g][j]);
-    t = fmaxf(t, __shfl_xor(t, 32, 64));
-    rebase(sa, m, t);
-    tmax[m] = 0.f;
-  }
-  if (n_kt > 1) lstore_k(1);
-  lstore_v(0);
-  __syncthreads();
-
-  // steady state at tile kt (parity PAR): LDS holds K(kt+1) [K buffer PAR^1] and V(kt) [V buffer PAR]
-  auto main_iter = [&](int kt, Scores& sc, Scores& sn, auto par_c) {   // needs kt + 2 < n_kt
-    constexpr int PAR = decltype(par_c)::value;
-#ifdef GWW_ATT_NOLOAD   // diagnostic: no K / V traffic in the steady state (wrong results)
-    if (kt < 0) {
-#endif
-    gload_k(kt + 2);
-    gload_v(kt + 1);
-#ifdef GWW_ATT_NOLOAD
-    }
-#endif
-    block(sc, sn, par_c, Yes{}, No{});
-    lstore_k(PAR);
-    lstore_v(PAR ^ 1);
-    __syncthreads();
-  };
-  auto prelast_iter = [&](int kt, Scores& sc, Scores& sn, auto par_c) {   // kt + 2 == n_kt
-    constexpr int PAR = decltype(par_c)::value;
-    gload_v(kt + 1);
-    if (ragged) block(sc, sn, par_c, Yes{}, Yes{});
-    else block(sc, sn, par_c, Yes{}, No{});
-    lstore_v(PAR ^ 1);
-    __syncthreads();
-  };
-  int kt = 0;
-  for (; kt + 3 < n_kt; kt += 2) {
-    main_iter(kt, sa, sb, P0{});
-    main_iter(kt + 1, sb, sa, P1{});
-  }
-  const int rem = n_kt - kt;   // 1, 2 or 3 tiles left, kt even, scores of tile kt in sa
-  if (rem == 3) {
-    main_iter(kt, sa, sb, P0{});
-    prelast_iter(kt + 1, sb, sa, P1{});
-    block(sa, sb, P0{}, No{}, No{});
-  } else if (rem == 2) {
-    prelast_iter(kt, sa, sb, P0{});
-    block(sb, sa, P1{}, No{}, No{});
-  } else {
-    block(sa, sb, P0{}, No{}, No{});
-  }
-
-#pragma unroll
-  for (int m = 0; m < MB; ++m) {
-    const float l_tot = lt[m][0];
-    const float inv = 1.0f / l_tot;
-    if (lse && q_row[m] < T && hh == 0)
-      lse[((long)b * H + h) * T + q_row[m]] = (m_run[m] + __log2f(l_tot)) * 0.69314718055994530942f;
-    if (q_row[m] < T) {
-      unsigned short* orow = ctx + ((long)b * T + q_row[m]) * d + h * DH;
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int dh = 32 * n + 8 * c + 4 * hh;
-          u32x2 o = {pack2bf(ot[m][n][4 * c] * inv, ot[m][n][4 * c + 1] * inv),
-                     pack2bf(ot[m][n][4 * c + 2] * inv, ot[m][n][4 * c + 3] * inv)};
-          *reinterpret_cast<u32x2*>(orow + dh) = o;
-        }
-    }
-  }
-}
-
 // last_tile_only: compute only the query tile that holds token T - 1 (the other rows of ctx are left untouched) --
 // the pooled forward needs nothing else of the last layer's attention.
-// q_log2: q was projected with log2(e) / 8 instead of 1 / 8 -> k_attention_l2_bf16 (reference through the matrix pipe).
-// attention_log2q_enabled(): whether the encoder's inference path packs its q panels that way (default; GWW_ATT_LOG2Q=0
-// falls back to natural-unit q and k_attention_bf16, the kernel the training forward uses).
-// GWW_ATT_PIPE=1: launch the experimental software-pipelined kernel for log2-unit q instead (measured slower: 1.20 ms
-// against 1.13 ms for k_attention_bf16 per whisper-tiny layer at B = 256 -- two waves per SIMD).
+// q_log2: q was projected with log2(e) / 8 instead of 1 / 8 (every bf16 q panel of the encoder is packed that way unless
+// GWW_ATT_LOG2Q=0) -> k_attention_dma_bf16 (default) or, GWW_ATT_VAR = 0 .. 3, the register-staged k_attention_l2_bf16.
+// Measured per whisper-tiny layer at B = 256 (tools/run/att_ab.py, interleaved in one process, three boxes):
+//   k_attention_bf16 (natural q, round 1)          1.16 - 1.25 ms
+//   k_attention_l2_bf16 VAR 0 / 2                  1.18 / 1.06 - 1.13   (VAR 1: 1.41 - 1.50, VAR 3: 1.19 - 1.21)
+//   k_attention_dma_bf16 VAR 4 / 5 / 6 / 7         1.00 - 1.06 / 1.08 / 1.07 - 1.12 / 1.02 - 1.04
+// (an earlier software-pipelined two-waves-per-SIMD kernel measured 1.20 ms and was removed.)
 bool attention_log2q_enabled() {
   static const bool off = getenv("GWW_ATT_LOG2Q") && atoi(getenv("GWW_ATT_LOG2Q")) == 0;
   return !off;
-}
-static bool attention_pipe_kernel() {
-  static const bool on = getenv("GWW_ATT_PIPE") && atoi(getenv("GWW_ATT_PIPE")) != 0;
-  return on;
 }
 
 int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipStream_t s, float* lse,
@@ -1131,43 +804,35 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
   GWW_REQUIRE(B >= 0 && T > 0 && H > 0, "attention_bf16: bad shape B=%d T=%d H=%d", B, T, H);
   GWW_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)ctx) & 15) == 0, "attention_bf16: 16-byte alignment");
   if (B == 0) return GWW_OK;
-  const int nw_env = getenv("GWW_ATT_WAVES") ? atoi(getenv("GWW_ATT_WAVES")) : 0;   // tuning aid: 4 or 8 (read per call)
-  // 128 query rows per workgroup, two workgroups per CU; the 256-row form (one per CU, K / V streamed once per
-  // 256 queries) measures 5 % slower at T = 1500 -- the kernel is issue-bound, not L2-bound
-  const bool pipe = q_log2 && attention_pipe_kernel();
-  const int nw = (nw_env == 8 && !pipe) ? 8 : 4;
-  static const int mb_env = getenv("GWW_ATT_MB") ? atoi(getenv("GWW_ATT_MB")) : 1;   // pipelined kernel: row blocks per wave
-  const int mb = pipe ? (mb_env == 2 ? 2 : 1) : 1;
-  const int all_tiles = (T + nw * 32 * mb - 1) / (nw * 32 * mb);
+  const int nw_env = getenv("GWW_ATT_WAVES") ? atoi(getenv("GWW_ATT_WAVES")) : 0;   // tuning aid (natural-q kernel): 4 or 8
+  const int nw = (nw_env == 8 && !q_log2) ? 8 : 4;
+  const int all_tiles = (T + nw * 32 - 1) / (nw * 32);
   const int q_tiles = last_tile_only ? 1 : all_tiles, qt0 = last_tile_only ? all_tiles - 1 : 0;
   const long blocks = (long)q_tiles * B * H;
   GWW_REQUIRE(blocks < 2147483647L, "attention_bf16: grid too large");
   const unsigned short* in = (const unsigned short*)qkv;
   unsigned short* out = (unsigned short*)ctx;
-  if (pipe && mb == 2)
-    hipLaunchKernelGGL((k_attention_pipe_bf16<4, 2>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0);
-  else if (pipe)
-    hipLaunchKernelGGL((k_attention_pipe_bf16<4, 1>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0);
-  else if (q_log2) {
-    const int var = getenv("GWW_ATT_VAR") ? atoi(getenv("GWW_ATT_VAR")) & 7 : 2;   // read per call: in-process A/B
-    if (var >= 4) {
-      const long blocks4 = (long)((last_tile_only ? 1 : (T + 127) / 128)) * B * H;
-      const int qt4 = last_tile_only ? (T + 127) / 128 - 1 : 0, nq4 = last_tile_only ? 1 : (T + 127) / 128;
-      if (var == 4) hipLaunchKernelGGL((k_attention_dma_bf16<3, false>), dim3((unsigned)blocks4), dim3(256), 0, s, in, out, lse, T, H, nq4, qt4);
-      else if (var == 5) hipLaunchKernelGGL((k_attention_dma_bf16<4, false>), dim3((unsigned)blocks4), dim3(256), 0, s, in, out, lse, T, H, nq4, qt4);
-      else hipLaunchKernelGGL((k_attention_dma_bf16<3, true>), dim3((unsigned)blocks4), dim3(256), 0, s, in, out, lse, T, H, nq4, qt4);
-      GWW_LAUNCH_CHECK();
-      return GWW_OK;
+  if (q_log2) {
+    const int var = getenv("GWW_ATT_VAR") ? atoi(getenv("GWW_ATT_VAR")) & 7 : 7;   // read per call: in-process A/B
+#define GWW_L2(VV) hipLaunchKernelGGL((k_attention_l2_bf16<4, VV>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0)
+#define GWW_DMA(MW, MS, NM) hipLaunchKernelGGL((k_attention_dma_bf16<MW, MS, NM>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0)
+    switch (var) {
+      case 0: GWW_L2(0); break;
+      case 1: GWW_L2(1); break;
+      case 2: GWW_L2(2); break;
+      case 3: GWW_L2(3); break;
+      case 4: GWW_DMA(3, false, false); break;
+      case 5: GWW_DMA(4, false, false); break;
+      case 6: GWW_DMA(3, true, false); break;
+      default: GWW_DMA(3, false, true); break;
     }
-#define GWW_L2(NWW, VV) hipLaunchKernelGGL((k_attention_l2_bf16<NWW, VV>), dim3((unsigned)blocks), dim3(NWW * 64), 0, s, in, out, lse, T, H, q_tiles, qt0)
-    if (nw == 8) { if (var == 0) GWW_L2(8, 0); else if (var == 1) GWW_L2(8, 1); else if (var == 2) GWW_L2(8, 2); else GWW_L2(8, 3); }
-    else { if (var == 0) GWW_L2(4, 0); else if (var == 1) GWW_L2(4, 1); else if (var == 2) GWW_L2(4, 2); else GWW_L2(4, 3); }
 #undef GWW_L2
-  }
-  else if (nw == 8)
+#undef GWW_DMA
+  } else if (nw == 8) {
     hipLaunchKernelGGL(k_attention_bf16<8>, dim3((unsigned)blocks), dim3(512), 0, s, in, out, lse, T, H, q_tiles, qt0);
-  else
+  } else {
     hipLaunchKernelGGL(k_attention_bf16<4>, dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0);
+  }
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const unsigned short* __
                                                         const float* __restrict__ lse,
                                                         const float* __restrict__ Dv,
                                                         unsigned short* __restrict__ dqkv, int T, int H,
-                                                        int q_tiles, const unsigned int* __restrict__ nz) {
+                                                        int q_tiles, const unsigned int* __restrict__ nz,
+                                                        float ssc, float gsc) {
   // per stage: K row image, K transposed-read image, V row image
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 3 * TILE_BYTES];   // 48 KB
   auto Kr = [&](int buf) -> unsigned char* { return lds + (buf * 3 + 0) * TILE_BYTES; };
@@ -189,8 +190,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const unsigned short* __
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int key = kt * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
-        const float p = (key < T) ? __builtin_amdgcn_exp2f(fmaf(st[j], kLog2e, -lse_q)) : 0.f;
-        st[j] = p * (dpt[j] - D_q);
+        const float p = (key < T) ? __builtin_amdgcn_exp2f(fmaf(st[j], ssc, -lse_q)) : 0.f;
+        st[j] = p * (dpt[j] - D_q) * gsc;
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
                                                          const float* __restrict__ lse,
                                                          const float* __restrict__ Dv,
                                                          unsigned short* __restrict__ dqkv, int T, int H,
-                                                         int k_tiles, const unsigned int* __restrict__ nz) {
+                                                         int k_tiles, const unsigned int* __restrict__ nz,
+                                                         float ssc, float gsc) {
   // per stage: Q row image, Q transposed-read image, dO row image, dO transposed-read image, lse[64], D[64]
   constexpr int STAGE = 4 * TILE_BYTES + 512;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];   // 65 KB
@@ -330,9 +332,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
         const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sm[4 * c + e], kLog2e, -ll[e]));
+          const float p = __builtin_amdgcn_exp2f(fmaf(sm[4 * c + e], ssc, -ll[e]));
           sm[4 * c + e] = p;
-          ds[4 * c + e] = p * (dpm[4 * c + e] - dd[e]);
+          ds[4 * c + e] = p * (dpm[4 * c + e] - dd[e]) * gsc;
         }
       }
 #pragma unroll
@@ -367,8 +369,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
 
 // qkv, ctx, dctx bf16; lse [B,H,T] from the forward; D scratch of B H (T + ceil(T / 64)) floats (row dots, then
 // the live-tile flags); dqkv [B,T,3d] out
+// q_log2: the q section of qkv is in log2 units (projected with log2(e) / 8, what the forward kernels of attention.hip
+// take): S = q_l2 k / log2(e), so P = exp2(q_l2 k - lse log2(e)) needs no multiply and dS is scaled by 1 / log2(e) once --
+// dq then is the gradient with respect to the STORED q (dS K / log2(e)) and dk = dS^T q_l2 / log2(e).
 int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* D,
-                              void* dqkv, int B, int T, int H, hipStream_t s) {
+                              void* dqkv, int B, int T, int H, hipStream_t s, bool q_log2) {
+  const float ssc = q_log2 ? 1.0f : kLog2e, gsc = q_log2 ? 1.0f / kLog2e : 1.0f;
   GWW_REQUIRE(qkv && ctx && dctx && lse && D && dqkv, "attention_bwd: NULL operand");
   GWW_REQUIRE(B >= 0 && T > 0 && H > 0, "attention_bwd: bad shape");
   if (B == 0) return GWW_OK;
@@ -382,10 +388,10 @@ int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx
   const long blocks = (long)tiles * B * H;
   GWW_REQUIRE(blocks < 2147483647L, "attention_bwd: grid too large");
   hipLaunchKernelGGL(k_attn_bwd_dq, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)qkv,
-                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles, nz);
+                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles, nz, ssc, gsc);
   GWW_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_attn_bwd_dkv, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)qkv,
-                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles, nz);
+                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles, nz, ssc, gsc);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }
@@ -396,5 +402,9 @@ using namespace gww;
 
 extern "C" int gww_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse,
                                       float* d_scratch, void* dqkv, int B, int T, int n_heads, void* stream) {
-  return launch_attention_bwd_bf16(qkv, ctx, dctx, lse, d_scratch, dqkv, B, T, n_heads, (hipStream_t)stream);
+  return launch_attention_bwd_bf16(qkv, ctx, dctx, lse, d_scratch, dqkv, B, T, n_heads, (hipStream_t)stream, false);
+}
+extern "C" int gww_attention_bwd_log2q_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                                            float* d_scratch, void* dqkv, int B, int T, int n_heads, void* stream) {
+  return launch_attention_bwd_bf16(qkv, ctx, dctx, lse, d_scratch, dqkv, B, T, n_heads, (hipStream_t)stream, true);
 }

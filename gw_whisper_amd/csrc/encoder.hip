@@ -45,7 +45,7 @@ int launch_dora_grads_multi(const void* X, long ldx, const void* dY, const void*
                             float* const* dm, long M, int d, hipStream_t s, void* scratch, size_t scratch_bytes);
 size_t dora_grads_scratch_bytes(int np, int d);
 int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* D,
-                              void* dqkv, int B, int T, int H, hipStream_t s);
+                              void* dqkv, int B, int T, int H, hipStream_t s, bool q_log2);
 int launch_mel_to_tokens(const float* mel, void* out, int out_bf16, int B, int C, int T, hipStream_t s);
 }
 
@@ -59,6 +59,7 @@ struct LayerW {
   // fp32 panels (parity path)
   float *wqkv32, *wo32, *w132, *w232;
   float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
+  float* bqkv16;   // q | k | v bias of the bf16 panels: the q part carries log2(e) like the packed bf16 q weights
   // LayerNorm-folded panels for the A-stationary GEMMs (gain folded into W, see gemm_astat.hip)
   unsigned short *wqkv_ln, *w1_ln;
   unsigned short* wmlp;   // fused-MLP weight stream (d = 384): mlp_fused.hip
@@ -118,7 +119,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
   const size_t o_c1wT = take((size_t)d * kConv1Kpad * 2), o_c2wT = take((size_t)d * 3 * d * 2);
   const size_t o_c1b = take(d * 4), o_c2b = take(d * 4), o_pos = take((size_t)T * d * 4);
   const size_t o_lnw = take(d * 4), o_lnb = take(d * 4);
-  struct LO { size_t wqkv, wo, w1, w2, wqkv32, wo32, w132, w232, bqkv, bo, b1, b2, ln1w, ln1b, ln2w, ln2b,
+  struct LO { size_t wqkv, wo, w1, w2, wqkv32, wo32, w132, w232, bqkv, bqkv16, bo, b1, b2, ln1w, ln1b, ln2w, ln2b,
                      wqkv_ln, w1_ln, uqkv, cbqkv, u1, cb1, wqkvT, woT, w1T, w2T, wmlp; };
   std::vector<LO> lo(L);
   for (int i = 0; i < L; ++i) {
@@ -131,6 +132,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
     lo[i].w132 = take((size_t)F * d * 4);
     lo[i].w232 = take((size_t)d * F * 4);
     lo[i].bqkv = take(3 * d * 4);
+    lo[i].bqkv16 = take(3 * d * 4);
     lo[i].bo = take(d * 4);
     lo[i].b1 = take(F * 4);
     lo[i].b2 = take(d * 4);
@@ -180,6 +182,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
     w.w132 = (float*)(p + lo[i].w132);
     w.w232 = (float*)(p + lo[i].w232);
     w.bqkv = (float*)(p + lo[i].bqkv);
+    w.bqkv16 = (float*)(p + lo[i].bqkv16);
     w.bo = (float*)(p + lo[i].bo);
     w.b1 = (float*)(p + lo[i].b1);
     w.b2 = (float*)(p + lo[i].b2);
@@ -290,19 +293,26 @@ static int pack_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_
     if (m & 1u) {
       GWW_REQUIRE(L.ln1_w && L.ln1_b && L.q_w && L.q_b && L.k_w && L.v_w && L.v_b,
                   "gww_encoder_set_weights: NULL attention weight in layer %d", i);
-      GWW_TRY(pack(L.q_w, w.wqkv, w.wqkv32, d, d, 1, d, qs));
+      // q in LOG2 UNITS on every bf16 panel (forward kernels of attention.hip: p = exp2(s) with no multiply per score;
+      // attention_bwd.hip and the DoRA-gradient scale of q follow suit): log2(e) / 8 instead of 1 / 8.  The fp32 parity
+      // panels keep natural units.
+      const float qs16 = attention_log2q_enabled() ? qs * 1.44269504088896340736f : qs;
+      GWW_TRY(launch_pack_weight(L.q_w, w.wqkv, 1, d, d, 1, d, qs16, s));
+      GWW_TRY(launch_pack_weight(L.q_w, w.wqkv32, 0, d, d, 1, d, qs, s));
       GWW_TRY(pack(L.k_w, w.wqkv + dd, w.wqkv32 + dd, d, d, 1, d, 1.f));
       GWW_TRY(pack(L.v_w, w.wqkv + 2 * dd, w.wqkv32 + 2 * dd, d, d, 1, d, 1.f));
       GWW_TRY(launch_scale_copy(L.q_b, w.bqkv, d, qs, s));
       GWW_TRY(launch_scale_copy(nullptr, w.bqkv + d, d, 0.f, s));   // k_proj has no bias
       GWW_TRY(launch_scale_copy(L.v_b, w.bqkv + 2 * d, d, 1.f, s));
+      GWW_TRY(launch_scale_copy(L.q_b, w.bqkv16, d, qs16, s));
+      GWW_TRY(launch_scale_copy(nullptr, w.bqkv16 + d, d, 0.f, s));
+      GWW_TRY(launch_scale_copy(L.v_b, w.bqkv16 + 2 * d, d, 1.f, s));
       GWW_TRY(launch_scale_copy(L.ln1_w, w.ln1w, d, 1.f, s));
       GWW_TRY(launch_scale_copy(L.ln1_b, w.ln1b, d, 1.f, s));
       // gain-folded panel + correction vectors for the algebraic LayerNorm of the A-stationary GEMM
       // (the A-stationary inference path feeds k_attention_l2_bf16, which takes q in log2 units: log2(e) rides in
       // the q panel, one rounding of the fp32 product instead of a second one on bf16 q)
-      GWW_TRY(launch_ln_fold(L.q_w, L.ln1_w, L.ln1_b, L.q_b, attention_log2q_enabled() ? qs * 1.44269504088896340736f : qs,
-                             d, d, w.wqkv_ln, w.uqkv, w.cbqkv, s));
+      GWW_TRY(launch_ln_fold(L.q_w, L.ln1_w, L.ln1_b, L.q_b, qs16, d, d, w.wqkv_ln, w.uqkv, w.cbqkv, s));
       GWW_TRY(launch_ln_fold(L.k_w, L.ln1_w, L.ln1_b, nullptr, 1.f, d, d, w.wqkv_ln + dd, w.uqkv + d, w.cbqkv + d, s));
       GWW_TRY(launch_ln_fold(L.v_w, L.ln1_w, L.ln1_b, L.v_b, 1.f, d, d, w.wqkv_ln + 2 * dd, w.uqkv + 2 * d,
                              w.cbqkv + 2 * d, s));
@@ -573,9 +583,9 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
     for (int i = 0; i < e->cfg.n_layers; ++i) {
       const LayerW& L = e->layers[i];
       TR(TR_LN, launch_layernorm(x, L.ln1w, L.ln1b, h, bf ? 1 : 0, M, d, s));
-      TR(TR_QKV, gemm(h, d, L.wqkv, L.wqkv32, L.bqkv, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0));
+      TR(TR_QKV, gemm(h, d, L.wqkv, L.wqkv32, bf ? L.bqkv16 : L.bqkv, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0));
       if (pooled_g && i == e->cfg.n_layers - 1) {
-        TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s, nullptr, /*last_tile_only=*/true));
+        TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s, nullptr, /*last_tile_only=*/true, q_log2));
         float* xs2 = (float*)(base + w.x2);    // [B, d] x rows (b, T-1) | x_mid | layer output
         float* xl = xs2;
         float* xm = xs2 + (size_t)B * d;
@@ -590,7 +600,7 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
         TR(TR_LNROWS, launch_layernorm_rows(xf, d, e->lnw, e->lnb, last_token, B, d, s, nullptr));
         return GWW_OK;
       }
-      if (bf) TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s));
+      if (bf) TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s, nullptr, false, q_log2));
       else TR(TR_ATTN, launch_attention_f32((const float*)qkv, (float*)ctx, B, T, H, s));
       TR(TR_OUT, gemm(ctx, d, L.wo, L.wo32, L.bo, x, nullptr, x, M, d, d, EPI_RESID, 0));
       TR(TR_LN, launch_layernorm(x, L.ln2w, L.ln2b, h, bf ? 1 : 0, M, d, s));
@@ -751,9 +761,9 @@ extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int b
     float* x_mid = (float*)(lb + sl.x_mid);
     void* z = lb + sl.z;
     GWW_TRY(launch_layernorm(x_in(l), W.ln1w, W.ln1b, h1, 1, M, d, s));
-    if (fast) GWW_TRY(launch_gemm_astat(h1, d, nullptr, nullptr, nullptr, nullptr, W.wqkv, W.bqkv, qkv, M, 3 * d, d, EPI_BIAS, 0, s));
-    else GWW_TRY(launch_gemm_bf16(h1, d, W.wqkv, W.bqkv, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0, s, 1));
-    GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s, lse));
+    if (fast) GWW_TRY(launch_gemm_astat(h1, d, nullptr, nullptr, nullptr, nullptr, W.wqkv, W.bqkv16, qkv, M, 3 * d, d, EPI_BIAS, 0, s));
+    else GWW_TRY(launch_gemm_bf16(h1, d, W.wqkv, W.bqkv16, nullptr, nullptr, qkv, M, 3 * d, d, EPI_BIAS, 0, s, 1));
+    GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s, lse, false, attention_log2q_enabled()));
     if (pooled && l == L - 1) {
       // Only token T-1 of the output is used (Signal_vs_Noise/src/model.py:25-26), and past the last attention
       // every op is row-wise: run out_proj / LN2 / fc1 / GELU / fc2 / final LN on the B last-token rows alone.
@@ -826,6 +836,8 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
       return launch_gemm_fulln(A, lda, Wt, nullptr, nullptr, Cout, M, N, K, EPI_BIAS, 0, s);
     return launch_gemm_bf16(A, lda, Wt, nullptr, nullptr, nullptr, Cout, M, N, K, EPI_BIAS, 0, s, 1);
   };
+  // the stored q is  q_ysc * (W' x + b): 1 / 8 (head_dim^-0.5), times log2(e) when the bf16 panels carry log2 units
+  const float q_ysc = attention_log2q_enabled() ? 0.125f * 1.44269504088896340736f : 0.125f;
   bool multi_ok = (d == 384 || d == 512) && !getenv("GWW_DORA_OLD");
   for (int i = 0; i < n_targets; ++i) multi_ok = multi_ok && targets[i].r == 8;
   // final LayerNorm backward -> dx (grad w.r.t. x_in[L]); pooled: on the B last-token rows only
@@ -894,7 +906,7 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
     }
     GWW_TRY(gemm_dx(dxb, d, W.woT, dctx, d, d));
     }
-    GWW_TRY(launch_attention_bwd_bf16(qkv, ctx, dctx, lse, Dv, dqkv, B, T, H, s));
+    GWW_TRY(launch_attention_bwd_bf16(qkv, ctx, dctx, lse, Dv, dqkv, B, T, H, s, attention_log2q_enabled()));
     if (multi_ok) {
       // q / k / v adapters of this layer read the same h1: one pass over h1, dqkv and qkv on the matrix cores
       long off[3];
@@ -906,8 +918,8 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
         if (t.layer != l || t.proj == 3) continue;
         GWW_REQUIRE(np < 3, "gww_encoder_train_backward: duplicate q/k/v target in layer %d", l);
         off[np] = (long)t.proj * d;
-        bias[np] = W.bqkv + off[np];
-        ysc[np] = t.proj == 0 ? 0.125f : 1.0f;
+        bias[np] = W.bqkv16 + off[np];
+        ysc[np] = t.proj == 0 ? q_ysc : 1.0f;
         scl[np] = t.scaling;
         Aa[np] = t.A; Bb[np] = t.B; mg[np] = t.mag; nr[np] = t.nrm;
         dAa[np] = t.dA; dBb[np] = t.dB; dmm[np] = t.dm;
@@ -922,7 +934,7 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
         if (t.layer != l || t.proj == 3) continue;
         const long off = (long)t.proj * d;   // q | k | v section
         GWW_TRY(launch_dora_grads(h1, d, (const unsigned short*)dqkv + off, (const unsigned short*)qkv + off, 3L * d,
-                                  W.bqkv + off, t.proj == 0 ? 0.125f : 1.0f, t.scaling, t.A, t.B, t.mag, t.nrm, t.dA,
+                                  W.bqkv16 + off, t.proj == 0 ? q_ysc : 1.0f, t.scaling, t.A, t.B, t.mag, t.nrm, t.dA,
                                   t.dB, t.dm, M, d, t.r, s, base + w.dgs, w.dgs_bytes));
       }
     }

@@ -242,7 +242,7 @@ extern "C" int gww_qscan_interp_f32(const float* energy, long e_total, const int
 // PyTorch's adaptive pooling regions: rows [floor(f Hin / F), ceil((f + 1) Hin / F)), columns likewise.
 namespace gww {
 namespace {
-constexpr int QT_MAXW = 1024;
+constexpr int QT_MAXW = 4096;
 __global__ __launch_bounds__(256) void k_qadapter_tail(const float* __restrict__ y, int Hin, int Win,
                                                        const float* __restrict__ scale, const float* __restrict__ bias,
                                                        const float* __restrict__ gamma_i, const float* __restrict__ beta_i,
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void k_qadapter_tail(const float* __restrict__
 }  // namespace gww
 
 // y: fp32 [B, Hin, Win]; scale, bias, gamma_i, beta_i: device scalars (gamma_i / beta_i already point at detector i);
-// out: fp32, element (b, f, t) at out[b * out_batch_stride + f * T + t].  T % 4 == 0, Win <= 1024, out 16-byte aligned.
+// out: fp32, element (b, f, t) at out[b * out_batch_stride + f * T + t].  T % 4 == 0, Win <= 4096, out 16-byte aligned.
 extern "C" int gww_qadapter_tail_f32(const float* y, int B, int Hin, int Win, const float* scale, const float* bias,
                                      const float* gamma_i, const float* beta_i, float* out, long out_batch_stride,
                                      int F, int T, void* stream) {

@@ -226,8 +226,8 @@ def attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:
 
 
 def attention_log2q(qkv: torch.Tensor, n_heads: int, want_lse: bool = False):
-    """The software-pipelined bf16 kernel of the encoder's fast path: like :func:`attention`, but the q section is
-    in log2 units (projected with log2(e) / 8 instead of 1 / 8).  Returns ctx, or (ctx, lse [B, H, T] natural log)."""
+    """The attention kernel of the encoder's bf16 paths: like :func:`attention`, but the q section is in log2 units
+    (projected with log2(e) / 8 instead of 1 / 8).  Returns ctx, or (ctx, lse [B, H, T] natural log)."""
     qkv = _dev(qkv, torch.bfloat16, "qkv")
     B, T, d3 = qkv.shape
     if d3 != 3 * n_heads * 64:
@@ -269,17 +269,18 @@ def attention_lse(qkv: torch.Tensor, n_heads: int):
     return ctx, lse
 
 
-def attention_bwd(qkv, ctx, dctx, lse, n_heads: int) -> torch.Tensor:
-    """dqkv [B, T, 3 d] (bf16) of softmax(q k^T) v given dctx."""
+def attention_bwd(qkv, ctx, dctx, lse, n_heads: int, q_log2: bool = False) -> torch.Tensor:
+    """dqkv [B, T, 3 d] (bf16) of softmax(q k^T) v given dctx; ``q_log2``: the q section is in log2 units and its
+    gradient is taken with respect to that stored q."""
     qkv, ctx, dctx = (_dev(t, torch.bfloat16) for t in (qkv, ctx, dctx))
     lse = _dev(lse, torch.float32, "lse")
     B, T, d3 = qkv.shape
     dqkv = torch.empty_like(qkv)
     scratch = torch.empty(B * n_heads * (T + (T + 63) // 64), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        check(lib().gww_attention_bwd_bf16(qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(),
-                                           scratch.data_ptr(), dqkv.data_ptr(), B, T, n_heads, _stream()),
-              "gww_attention_bwd_bf16")
+        fn = lib().gww_attention_bwd_log2q_bf16 if q_log2 else lib().gww_attention_bwd_bf16
+        check(fn(qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(), scratch.data_ptr(), dqkv.data_ptr(),
+                 B, T, n_heads, _stream()), "gww_attention_bwd_bf16")
     return dqkv
 
 

@@ -18,7 +18,8 @@ Device work:
   resolution, ``q = ifft(1 / sqrt(psd))``, hann-tapered truncation to ``max_filter_duration``, ``|fft(q)|`` -- in fp64
   with the N-point transforms of ``torch.fft`` (rocFFT); the result is read off as the impulse response
   ``h = irfft(|fft(q)|)``, which is ``max_filter_len`` taps long up to the tail the modulus adds (kept until it is below
-  1e-9 of the response).
+  1e-6 of the response; with a low-frequency cutoff the rectified stop-band ripple can make it too long for the FIR form
+  (> 8191 taps): the response is then applied with the N-point transform, as the reference does).
 * Filter application: ``gww_fir_f32`` -- the strain streams once through LDS against those taps (time domain, O(1)
   extra memory; circular padding reproduces the reference's circular convolution exactly) and the
   ``max_filter_len // 2`` corrupted samples on each side are never computed.
@@ -98,11 +99,15 @@ def welch_median_psd(x: torch.Tensor, delta_t: float, segment_duration: float):
     return out, delta_f
 
 
+K_MAX = 4095          # longest half-length of the time-domain form (gww_fir_f32 takes up to 16384 taps)
+
+
 def design_filter(psd_w: torch.Tensor, delta_f_w: float, n: int, delta_t: float, max_filter_len: int,
-                  low_frequency_cutoff=None, trunc_method="hann", tail: float = 1e-9):
+                  low_frequency_cutoff=None, trunc_method="hann", tail: float = 1e-6):
     """PyCBC's ``interpolate`` + ``inverse_spectrum_truncation`` for every row of psd_w (fp64 [D, bins]) at the resolution of an
     n-sample segment; returns the correlation taps g fp32 [D, taps4] (zero padded to a multiple of 4) and K with
-    ``white[i] = sum_u g[u] x[(i - K + u) mod n]``."""
+    ``white[i] = sum_u g[u] x[(i - K + u) mod n]`` -- or ``(None, wf)`` with the frequency response ``|fft(q)|`` when the
+    response does not fit ``K_MAX`` taps to within ``tail`` of its l1 norm."""
     D, bins = psd_w.shape
     dev = psd_w.device
     delta_f = 1.0 / (n * delta_t)
@@ -130,15 +135,18 @@ def design_filter(psd_w: torch.Tensor, delta_f_w: float, n: int, delta_t: float,
         q[:, t0:t1] = 0
     wf = (torch.fft.rfft(q, dim=1) * delta_t).abs()                 # (1 / psd_out) ** 0.5 = |fft(q)|
     h = torch.fft.irfft(wf.to(torch.complex128), n=N, dim=1)        # real, even: white = h (*) x circularly
-    # keep the central taps until the rest is negligible (max_filter_len // 2 each side + what the modulus spreads)
+    # keep the central taps until the rest is negligible (max_filter_len // 2 each side + what the modulus spreads: with a
+    # low-frequency cutoff the rectified stop-band ripple decays slowly).  No K <= K_MAX reaches `tail`: return the
+    # frequency response instead and let the caller apply it with the N-point transform.
     K = max(t0, 64)
     total = h.abs().sum(dim=1)
-    while K < N // 2 - 1:
+    while True:
         rest = total - h[:, :K + 1].abs().sum(dim=1) - h[:, N - K:].abs().sum(dim=1)
         if float((rest / total).max()) < tail:
             break
+        if 2 * K > K_MAX or 2 * K >= N // 2 - 1:
+            return None, wf
         K *= 2
-    K = min(K, N // 2 - 1)
     taps = torch.cat((h[:, N - K:], h[:, :K + 1]), dim=1)            # h[-K .. K]
     g = taps.flip(1)                                                 # g[u] = h[K - u]
     taps4 = (g.shape[1] + 3) // 4 * 4
@@ -175,6 +183,15 @@ def whiten(strain, delta_t: float = 1.0 / 2048.0, segment_duration: float = 0.5,
     g, K = design_filter(psd_w, df_w, n, delta_t, max_filter_len, low_frequency_cutoff, trunc_method)
     cut = max_filter_len // 2 if remove_corrupted else 0
     n_out = n - 2 * cut
+    if g is None:
+        # long response (low-frequency cutoff): the reference's own form, irfft(rfft(x) |fft(q)|), in fp64 (rocFFT)
+        white = torch.fft.irfft(torch.fft.rfft(xs.double(), dim=1) * K, n=n, dim=1)[:, cut:n - cut].float().contiguous()
+        if one_d:
+            white = white[0]
+        if return_psd:
+            p = psd_w / (scale * scale)
+            return white, (p[0] if one_d else p)
+        return white
     # circular padding: output i (= sample cut + i) needs x[(cut + i - K + u) mod n], u = 0 .. 2 K
     idx = (torch.arange(n_out + g.shape[1], device=x.device) + (cut - K)) % n
     pad = (n_out + g.shape[1] + 3) // 4 * 4

@@ -264,7 +264,7 @@ int gww_qscan_interp_f32(const float* energy, long e_total, const int* rows, con
  * AdaptiveAvgPool2d((F, T)) of the adapter CNN's output y fp32 [B, Hin, Win], then scale * y + bias, then
  * * film_gamma[i] + film_beta[i]; the result goes straight into the stacked [B, D, F, T] feature tensor: element
  * (b, f, t) at out[b * out_batch_stride + f * T + t] (the caller offsets `out` to detector i).  scale / bias / gamma_i /
- * beta_i are device scalars (no host sync).  T % 4 == 0, Win <= 1024. */
+ * beta_i are device scalars (no host sync).  T % 4 == 0, Win <= 4096. */
 int gww_qadapter_tail_f32(const float* y, int B, int Hin, int Win, const float* scale, const float* bias,
                           const float* gamma_i, const float* beta_i, float* out, long out_batch_stride, int F, int T,
                           void* stream);
@@ -284,15 +284,19 @@ int gww_gemm_f32(const float* A, const float* W, const float* bias, const float*
 /* softmax(q k^T) v per head, q pre-scaled; qkv [B,T,3*d] (q|k|v), ctx [B,T,d]; head_dim 64 */
 int gww_attention_bf16(const void* qkv, void* ctx, int B, int T, int n_heads, void* stream);
 int gww_attention_f32(const float* qkv, float* ctx, int B, int T, int n_heads, void* stream);
-/* experimental software-pipelined bf16 kernel (off by default; the encoder launches it only under GWW_ATT_PIPE=1):
- * q must be in log2 units, i.e. projected with log2(e) / 8 instead of 1 / 8 (gww_encoder_set_weights folds that into
- * the packed q panel when the switch is on); lse optional, natural log */
+/* the kernel of the encoder's bf16 paths (k_attention_dma_bf16): q must be in log2 units, i.e. projected with
+ * log2(e) / 8 instead of 1 / 8 (gww_encoder_set_weights folds that into every packed bf16 q panel); the running
+ * reference enters the score accumulators through one extra MFMA, K / V tiles by LDS-DMA; lse optional, natural log */
 int gww_attention_log2q_bf16(const void* qkv, void* ctx, float* lse_or_null, int B, int T, int n_heads, void* stream);
 /* attention backward: dqkv [B,T,3d] from qkv, ctx (forward output), dctx and the forward's lse [B,H,T]
  * (gww_attention_lse_bf16 below); d_scratch: B * H * (T + ceil(T / 64)) fp32 words (row dots + live-tile flags:
  * query tiles whose dctx rows are all zero are skipped, which is most of them under last-token pooling) */
 int gww_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse,
                            float* d_scratch, void* dqkv, int B, int T, int n_heads, void* stream);
+/* the same for a q section in log2 units (projected with log2(e) / 8, what gww_attention_log2q_bf16 takes): the q
+ * section of dqkv is the gradient with respect to that stored q */
+int gww_attention_bwd_log2q_bf16(const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                                 float* d_scratch, void* dqkv, int B, int T, int n_heads, void* stream);
 /* forward attention that also returns the row log-sum-exp lse [B,H,T] */
 int gww_attention_lse_bf16(const void* qkv, void* ctx, float* lse, int B, int T, int n_heads, void* stream);
 /* LayerNorm backward: dx (+)= dLN/dx . dy   (dy fp32 or bf16; optional bf16 copy of the result) */

@@ -285,21 +285,19 @@ def _attn_ref_log2q(qkv_l2, H):
     return o.transpose(0, 2, 1, 3).reshape(B, Tn, d)
 
 
-@pytest.fixture(params=["l2", "l2_var0", "l2_var1", "l2_var3", "l2_var4", "l2_var5", "l2_var6", "l2_8waves"])
+@pytest.fixture(params=["default", "var0", "var1", "var2", "var3", "var4", "var5", "var6"])
 def att_variant(request, monkeypatch):
-    """k_attention_l2_bf16 (the inference path's kernel) and its tuning variants; the launcher reads GWW_ATT_VAR /
-    GWW_ATT_WAVES per call."""
+    """The log2-unit-q kernels: k_attention_dma_bf16 (default = GWW_ATT_VAR 7; 4 .. 6 its variants) and the
+    register-staged k_attention_l2_bf16 (0 .. 3); the launcher reads GWW_ATT_VAR per call."""
     v = request.param
-    if v.startswith("l2_var"):
+    if v.startswith("var"):
         monkeypatch.setenv("GWW_ATT_VAR", v[-1])
-    elif v == "l2_8waves":
-        monkeypatch.setenv("GWW_ATT_WAVES", "8")
     return v
 
 
 @pytest.mark.parametrize("B,Tn,H", [(1, 64, 1), (1, 37, 1), (2, 200, 2), (1, 128, 1), (1, 192, 2), (1, 1500, 2),
                                     (3, 129, 6), (2, 257, 1), (1, 1, 1), (2, 65, 2)])
-def test_attention_pipelined_log2q(T, gww, att_variant, B, Tn, H):
+def test_attention_log2q(T, gww, att_variant, B, Tn, H):
     """The log2-unit-q kernel (reference through the matrix pipe, first tile re-based, deferred re-basing later):
     one, two, three ... tiles, ragged and full last tiles, a single key, and the log-sum-exp it hands to
     training-style consumers."""
@@ -352,7 +350,7 @@ def test_attention_log2q_staircase_rebases_at_every_tile(T, gww, att_variant):
     np.testing.assert_allclose(got, ref, atol=6e-3, rtol=2 ** -7)
 
 
-def test_attention_pipelined_spike_forces_rebase(T, gww, att_variant):
+def test_attention_log2q_spike_forces_rebase(T, gww, att_variant):
     """A key far above the running reference late in the sequence (score 256): O, l AND the scores of the tile
     computed against the old reference must move to the new one; then a long tail of small scores."""
     from gw_whisper_amd import ops

@@ -70,6 +70,34 @@ def test_attention_backward(T, gww, B, Tn, H):
     assert np.sqrt(((dqkv - dqkv_ref) ** 2).mean()) < 3e-3 * scale
 
 
+@pytest.mark.parametrize("B,Tn,H", [(1, 64, 1), (2, 200, 2), (1, 1500, 2)])
+def test_attention_backward_log2_unit_q(T, gww, B, Tn, H):
+    """The same backward for a q section stored in log2 units (what the forward kernels of the inference AND training
+    paths take): P = exp2(q_l2 k - lse log2 e); dq is the gradient with respect to the stored q (the natural-unit
+    gradient / log2 e), dk and dv are unchanged."""
+    from gw_whisper_amd import ops
+    c = 1.4426950408889634
+    rng = np.random.default_rng(B * 100 + Tn + H)
+    d = H * 64
+    qkv = _bf(rng.standard_normal((B, Tn, 3 * d)) * 0.6)
+    qkv_l2 = qkv.copy()
+    qkv_l2[..., :d] = _bf(qkv[..., :d].astype(np.float64) * c)
+    nat = qkv_l2.astype(np.float64)
+    nat[..., :d] /= c                                   # the natural-unit q the stored one stands for
+    dctx = _bf(rng.standard_normal((B, Tn, d)) * 0.5)
+    ctx_ref, lse_ref, dqkv_ref = _attn_grads(nat, dctx.astype(np.float64), H)
+    dqkv_ref[..., :d] /= c
+    q = T.from_numpy(qkv_l2).cuda().bfloat16()
+    ctx, lse = ops.attention_log2q(q, H, want_lse=True)
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref, atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(ctx.float().cpu().numpy(), ctx_ref, atol=6e-3, rtol=2 ** -7)
+    dqkv = ops.attention_bwd(q, ctx, T.from_numpy(dctx).cuda().bfloat16(), lse, H, q_log2=True).float().cpu().numpy()
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        scale = np.abs(dqkv_ref[..., sl]).max()
+        assert np.abs(dqkv[..., sl] - dqkv_ref[..., sl]).max() < 2e-2 * scale, name
+        assert np.sqrt(((dqkv[..., sl] - dqkv_ref[..., sl]) ** 2).mean()) < 3e-3 * scale, name
+
+
 @pytest.mark.parametrize("B,Tn,H,live", [(2, 1500, 2, "last"), (1, 333, 1, "middle"), (1, 200, 2, "none"),
                                           (2, 1500, 1, "one_head")])
 def test_attention_backward_sparse_dctx(T, gww, B, Tn, H, live):
