@@ -33,7 +33,9 @@ int launch_mlp_pack(const void* w1_folded, const void* w2, const void* wqkv_fold
                     hipStream_t s);
 int launch_mlp_fused(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
                      const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s,
-                     const float* q_u = nullptr, const float* q_cb = nullptr, void* q_out = nullptr, int NQ = 0);
+                     const float* q_u = nullptr, const float* q_cb = nullptr, void* q_out = nullptr, int NQ = 0,
+                     float* x_next_out = nullptr);
+int launch_add_delta_f32(const float* x, const void* delta_bf16, float* out, long n, hipStream_t s);
 int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
                       float yscale, float scaling, const float* A, const float* Bm, const float* mag,
                       const float* nrm, float* dA, float* dB, float* dm, long M, int d, int r, hipStream_t s,
@@ -684,7 +686,7 @@ SavedLayout saved_layout(const gww_enc_cfg& c, int B) {
   return s;
 }
 struct TrainWs {
-  size_t melT, c1, h2, f1, dx, dxb, dbig, dh, dctx, dqkv, Dv, z1, col1, dgs, dgs_bytes, total;
+  size_t melT, c1, h2, f1, d2, dx, dxb, dbig, dh, dctx, dqkv, Dv, z1, col1, dgs, dgs_bytes, total;
 };
 TrainWs train_ws(const gww_enc_cfg& c, int B) {
   const size_t d = c.d_model, F = c.ffn, Tin = c.t_in, T = c.t_in / 2, C = c.n_mels, H = c.n_heads;
@@ -694,8 +696,9 @@ TrainWs train_ws(const gww_enc_cfg& c, int B) {
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
   w.melT = take(((size_t)B * (Tin + 2) * C + kConv1Kpad) * 2);
   w.c1 = take((((size_t)B * (Tin + 2) + 255) / 256 * 256 + 2) * d * 2);
-  w.h2 = take(Mp * d * 2);
-  w.f1 = take(Mp * F * 2);
+  w.h2 = take(Mp * d * 2);      // per-op path: LN2 output; fused path: out_proj delta (fwd), recomputed LN1 output (bwd)
+  w.f1 = take(Mp * F * 2);      // per-op path: gelu(fc1); fused path: recomputed pre-GELU fc1 output (bwd)
+  w.d2 = take(Mp * d * 2);      // fused path: the last layer's fc2 delta
   w.dx = take(Mp * d * 4);
   w.dxb = take(Mp * d * 2);
   w.dbig = take(Mp * F * 2);
@@ -712,6 +715,12 @@ TrainWs train_ws(const gww_enc_cfg& c, int B) {
   return w;
 }
 }  // namespace
+
+// d = 384: the training forward runs on the fused inference kernels (GWW_TRAIN_FUSED=0: the per-op forward of round 1)
+static bool train_fused(const gww_enc_cfg& c) {
+  static const bool off = getenv("GWW_TRAIN_FUSED") && atoi(getenv("GWW_TRAIN_FUSED")) == 0;
+  return !off && c.d_model == 384 && c.ffn % 128 == 0 && c.ffn <= 1536;
+}
 
 extern "C" size_t gww_train_saved_bytes(const gww_encoder* e, int batch) {
   return (e && batch > 0) ? saved_layout(e->cfg, batch).total : 0;
@@ -746,11 +755,70 @@ extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int b
   GWW_TRY(launch_mel_to_tokens(mel, melT, 1, B, C, Tin, s));
   GWW_HIP(hipMemsetAsync((char*)melT + (size_t)B * (Tin + 2) * C * 2, 0, kConv1Kpad * 2, s));
   GWW_HIP(hipMemsetAsync(c1, 0, (size_t)d * 2, s));
-  GWW_TRY(launch_gemm_bf16(melT, C, e->c1w, e->c1b, nullptr, nullptr, c1, (long)B * (Tin + 2), d, kConv1Kpad, EPI_CONV1,
-                           Tin + 2, s, 0));
-  GWW_TRY(launch_gemm_bf16(c1, 2L * d, e->c2w, e->c2b, nullptr, e->pos, x_in(0), (long)B * (T + 1), d, 3 * d, EPI_CONV2,
-                           T + 1, s, 1));
+  if (train_fused(e->cfg)) {   // the inference stem kernels (A-stationary conv1, full-N conv2)
+    GWW_TRY(launch_gemm_astat(melT, C, nullptr, nullptr, nullptr, nullptr, e->c1w, e->c1b, c1, (long)B * (Tin + 2), d,
+                              kConv1Kpad, EPI_CONV1, Tin + 2, s));
+    GWW_TRY(launch_gemm_fulln(c1, 2L * d, e->c2w, e->c2b, e->pos, x_in(0), (long)B * (T + 1), d, 3 * d, EPI_CONV2, T + 1, s));
+  } else {
+    GWW_TRY(launch_gemm_bf16(melT, C, e->c1w, e->c1b, nullptr, nullptr, c1, (long)B * (Tin + 2), d, kConv1Kpad, EPI_CONV1,
+                             Tin + 2, s, 0));
+    GWW_TRY(launch_gemm_bf16(c1, 2L * d, e->c2w, e->c2b, nullptr, e->pos, x_in(0), (long)B * (T + 1), d, 3 * d, EPI_CONV2,
+                             T + 1, s, 1));
+  }
   const bool fast = (d == 384 || d == 512) && F % 128 == 0;   // A-stationary kernel for the K = d GEMMs without a residual
+  if (train_fused(e->cfg)) {
+    // ---- fused forward (d = 384): the INFERENCE kernels -- LayerNorm-folded A-stationary q/k/v GEMM for layer 0, flash
+    // attention (+ lse), out_proj as a bf16 delta, fused MLP + the next layer's LN1 + q/k/v -- writing what the
+    // backward needs straight into the arena: x_in[l], qkv, lse, ctx, x_mid (= x_in + out_proj, the fused kernel's
+    // x_new).  LN1 / LN2 outputs and the pre-GELU fc1 output are NOT kept: the backward recomputes them (that is what
+    // the reference's gradient_checkpointing_enable() at MLGWSC-1/train.py:662 trades, too).
+    void* d1 = h2;
+    void* d2 = base + w.d2;
+    const bool q_log2 = attention_log2q_enabled();
+    for (int l = 0; l < L; ++l) {
+      const LayerW& W = e->layers[l];
+      char* lb = sv + (size_t)l * sl.layer_stride;
+      void* qkv = lb + sl.qkv;
+      float* lse = (float*)(lb + sl.lse);
+      void* ctx = lb + sl.ctx;
+      float* x_mid = (float*)(lb + sl.x_mid);
+      void* z = lb + sl.z;
+      if (l == 0)
+        GWW_TRY(launch_gemm_astat(x_in(0), d, nullptr, nullptr, W.uqkv, W.cbqkv, W.wqkv_ln, nullptr, qkv, M, 3 * d, d,
+                                  EPI_BIAS, 0, s));
+      if (pooled && l == L - 1) {
+        // only the query tile that holds token T - 1 is needed (forward and backward): the other rows of ctx / lse stay
+        // zero so that the backward's row dots see finite values
+        GWW_HIP(hipMemsetAsync(ctx, 0, (size_t)M * d * 2, s));
+        GWW_HIP(hipMemsetAsync(lse, 0, (size_t)B * H * T * 4, s));
+        GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s, lse, /*last_tile_only=*/true, q_log2));
+        float* xl = (float*)(base + w.dx);
+        GWW_HIP(hipMemcpy2DAsync(xl, (size_t)d * 4, x_in(l) + (size_t)(T - 1) * d, (size_t)T * d * 4, (size_t)d * 4, B,
+                                 hipMemcpyDeviceToDevice, s));
+        GWW_TRY(launch_gemm_bf16((const unsigned short*)ctx + (size_t)(T - 1) * d, (long)T * d, W.wo, W.bo, xl, nullptr,
+                                 x_mid, B, d, d, EPI_RESID, 0, s, 0));
+        GWW_TRY(launch_layernorm(x_mid, W.ln2w, W.ln2b, d1, 1, B, d, s));
+        GWW_TRY(launch_gemm_bf16(d1, d, W.w1, W.b1, nullptr, nullptr, z, B, F, d, EPI_BIAS, 0, s, 0));
+        GWW_TRY(launch_gelu_bf16(z, nullptr, f1, (((long)B * F + 7) / 8) * 8, s));
+        GWW_TRY(launch_gemm_bf16(f1, F, W.w2, W.b2, x_mid, nullptr, x_in(L), B, d, F, EPI_RESID, 0, s, 0));
+        GWW_TRY(launch_layernorm(x_in(L), e->lnw, e->lnb, last_hidden, 0, B, d, s));
+        return GWW_OK;
+      }
+      GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s, lse, false, q_log2));
+      GWW_TRY(launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, W.wo, W.bo, d1, M, d, d, EPI_BIAS, 0, s));
+      if (l + 1 < L) {
+        const LayerW& Wn = e->layers[l + 1];
+        void* qkv_n = sv + (size_t)(l + 1) * sl.layer_stride + sl.qkv;
+        GWW_TRY(launch_mlp_fused(x_in(l), d1, x_mid, W.u1, W.cb1, W.wmlp, W.b2, nullptr, M, d, F, s, Wn.uqkv, Wn.cbqkv, qkv_n,
+                                 3 * d, x_in(l + 1)));
+      } else {
+        GWW_TRY(launch_mlp_fused(x_in(l), d1, x_mid, W.u1, W.cb1, W.wmlp, W.b2, d2, M, d, F, s));
+        GWW_TRY(launch_add_delta_f32(x_mid, d2, x_in(L), M * d, s));
+      }
+    }
+    GWW_TRY(launch_layernorm(x_in(L), e->lnw, e->lnb, last_hidden, 0, M, d, s));
+    return GWW_OK;
+  }
   for (int l = 0; l < L; ++l) {
     const LayerW& W = e->layers[l];
     char* lb = sv + (size_t)l * sl.layer_stride;
@@ -851,6 +919,17 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
     const void* ctx = lb + sl.ctx;
     const float* x_mid = (const float*)(lb + sl.x_mid);
     const void* z = lb + sl.z;
+    const bool fused = train_fused(e->cfg);
+    if (fused) {
+      // the fused forward kept neither LN1(x_in) (the X operand of the q / k / v adapter gradients) nor the pre-GELU
+      // fc1 output: recompute them into the workspace (LN kernel; LayerNorm-folded A-stationary fc1 GEMM, plain bias epilogue)
+      GWW_TRY(launch_layernorm(x_in(l), W.ln1w, W.ln1b, base + w.h2, 1, M, d, s));
+      h1 = base + w.h2;
+      if (!(pooled && l == L - 1)) {
+        GWW_TRY(launch_gemm_astat(x_mid, d, nullptr, nullptr, W.u1, W.cb1, W.w1_ln, nullptr, base + w.f1, M, F, d, EPI_BIAS, 0, s));
+        z = base + w.f1;
+      }
+    }
     if (pooled && l == L - 1) {
       // ---- last layer of a pooled step: everything above the attention lives on the B last-token rows
       // (x_mid, z, x_in[L] were saved compact by the pooled forward); the attention backward then sees a dctx

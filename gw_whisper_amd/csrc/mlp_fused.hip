@@ -115,7 +115,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
                                                             unsigned short* __restrict__ C, long M, int F,
                                                             int stagger_ticks, const float* __restrict__ q_u,
                                                             const float* __restrict__ q_cb,
-                                                            unsigned short* __restrict__ q_out, int NQ) {
+                                                            unsigned short* __restrict__ q_out, int NQ,
+                                                            float* x_next) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[MF_LDS];
   constexpr int MF_NST = PAIR ? MF_AHEAD + 2 : MF_AHEAD + 1;
   float* lds_cb = reinterpret_cast<float*>(lds + MF_OFF_CB);
@@ -497,7 +498,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     // ---- epilogue == prologue of the next layer's LN1 + QKV GEMM.  Per 64-column chunk np: the fc2 output (+ b2,
     // rounded to bf16 exactly like the stand-alone kernel's delta) goes through the wave-private slice into row
     // order, x_next = x_new + out is formed from whole-line re-reads of x_new (written by this wave in the
-    // prologue), written back IN PLACE, and shifted / measured / packed into the A fragments of k-tile np.
+    // prologue), written to x_next (== x_out, i.e. IN PLACE, on the inference path; a buffer of its own on the training
+    // path, which keeps x_new as x_mid), and shifted / measured / packed into the A fragments of k-tile np.
     // The tiles already in flight are older than these loads: hipcc's own vmcnt waits retire them first.
     {
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, cshift[4];
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #pragma unroll
               for (int i = 0; i < 4; ++i)
                 if (m_base + 8 * i + crow < M)
-                  *reinterpret_cast<f32x4*>(x_out + grow[i] * MF_D + 64 * (np - 2 + q) + 32 * h2 + 4 * cchunk) = xn4[q][h2][i];
+                  *reinterpret_cast<f32x4*>(x_next + grow[i] * MF_D + 64 * (np - 2 + q) + 32 * h2 + 4 * cchunk) = xn4[q][h2][i];
           asm volatile("" ::: "memory");
         }
       }
@@ -784,7 +786,7 @@ int launch_mlp_pack(const void* w1_folded, const void* w2, const void* wqkv_fold
 // 128-row panels are stored).
 int launch_mlp_fused(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
                      const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s,
-                     const float* q_u, const float* q_cb, void* q_out, int NQ) {
+                     const float* q_u, const float* q_cb, void* q_out, int NQ, float* x_next_out) {
   GWW_REQUIRE(x && delta && x_out && ln_u && ln_cb && Wt && b2, "mlp_fused: NULL operand");
   GWW_REQUIRE(d == MF_D, "mlp_fused: built for d_model = 384 (got %d)", d);
   GWW_REQUIRE(F % 128 == 0 && F > 0 && F <= MF_FMAX, "mlp_fused: ffn = %d must be a multiple of 128, <= 1536", F);
@@ -800,16 +802,20 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
   // stagger only when there is more than one round of workgroups to keep de-phased; 100 MHz ticks
   static const int stagger_env = getenv("GWW_MLP_STAGGER") ? atoi(getenv("GWW_MLP_STAGGER")) : 0;
   const int stagger = panels >= 512 ? stagger_env : 0;
-  const bool pair = !(getenv("GWW_MLP_PAIR") && atoi(getenv("GWW_MLP_PAIR")) == 0);   // read per call: in-process A/B
+  // one barrier per two weight tiles (PAIR) measured no different from one per tile (1.154 vs 1.159 ms plain, 1.653 vs
+  // 1.653 ms with the appended q/k/v, tools/run/mlp_ab.py): the round-1 form stays the default
+  const bool pair = getenv("GWW_MLP_PAIR") && atoi(getenv("GWW_MLP_PAIR")) != 0;   // read per call: in-process A/B
 #define GWW_MF_LAUNCH(QQ, PP, ...)                                                                                         \
   hipLaunchKernelGGL((k_mlp_fused<QQ, PP>), dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta, \
                      x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger, __VA_ARGS__)
   if (qkv) {
-    if (pair) GWW_MF_LAUNCH(true, true, q_u, q_cb, (unsigned short*)q_out, NQ);
-    else GWW_MF_LAUNCH(true, false, q_u, q_cb, (unsigned short*)q_out, NQ);
+    float* xnx = x_next_out ? x_next_out : x_out;
+    GWW_REQUIRE((((uintptr_t)xnx) & 15) == 0 && (const void*)xnx != (const void*)x, "mlp_fused: bad x_next_out");
+    if (pair) GWW_MF_LAUNCH(true, true, q_u, q_cb, (unsigned short*)q_out, NQ, xnx);
+    else GWW_MF_LAUNCH(true, false, q_u, q_cb, (unsigned short*)q_out, NQ, xnx);
   } else {
-    if (pair) GWW_MF_LAUNCH(false, true, nullptr, nullptr, nullptr, 0);
-    else GWW_MF_LAUNCH(false, false, nullptr, nullptr, nullptr, 0);
+    if (pair) GWW_MF_LAUNCH(false, true, nullptr, nullptr, nullptr, 0, nullptr);
+    else GWW_MF_LAUNCH(false, false, nullptr, nullptr, nullptr, 0, nullptr);
   }
 #undef GWW_MF_LAUNCH
   GWW_LAUNCH_CHECK();
@@ -842,5 +848,5 @@ extern "C" int gww_mlp_fused_bf16(const float* x, const void* delta, float* x_ou
                                   int F, const float* qkv_u, const float* qkv_cb, void* qkv_out, int NQ,
                                   void* stream) {
   return launch_mlp_fused(x, delta, x_out, ln_u, ln_cb, Wt, b2, C, M, d, F, (hipStream_t)stream, qkv_u, qkv_cb, qkv_out,
-                          NQ);
+                          NQ, nullptr);
 }

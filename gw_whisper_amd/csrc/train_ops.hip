@@ -308,6 +308,30 @@ __global__ __launch_bounds__(256) void k_sub_f32_bf16(const float* __restrict__ 
   }
 }
 
+// out = x + delta (fp32 residual stream + bf16 deferred delta): x_in[L] of the fused training forward
+__global__ __launch_bounds__(256) void k_add_delta_f32(const float* __restrict__ x, const unsigned short* __restrict__ dl,
+                                                       float* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    const u32x2 dv = reinterpret_cast<const u32x2*>(dl)[i];
+    v[0] += bf2f((unsigned short)(dv[0] & 0xffff));
+    v[1] += bf2f((unsigned short)(dv[0] >> 16));
+    v[2] += bf2f((unsigned short)(dv[1] & 0xffff));
+    v[3] += bf2f((unsigned short)(dv[1] >> 16));
+    reinterpret_cast<f32x4*>(out)[i] = v;
+  }
+}
+
+int launch_add_delta_f32(const float* x, const void* delta_bf16, float* out, long n, hipStream_t s) {
+  GWW_REQUIRE(n % 4 == 0, "add_delta_f32: n must be a multiple of 4");
+  if (n == 0) return GWW_OK;
+  long blocks = cdiv(n / 4, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_add_delta_f32, dim3((unsigned)blocks), dim3(256), 0, s, x, (const unsigned short*)delta_bf16, out, n / 4);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
 int launch_sub_f32_bf16(const float* a, const float* b, void* out, long n, hipStream_t s) {
   GWW_REQUIRE(n % 4 == 0, "sub_f32_bf16: n must be a multiple of 4");
   if (n == 0) return GWW_OK;

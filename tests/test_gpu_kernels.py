@@ -445,11 +445,11 @@ def test_mlp_pack_layout(T, gww):
                 np.testing.assert_array_equal(logical, w2n[128 * idx3 + row, 64 * cp:64 * cp + 64][sw])
 
 
-@pytest.fixture(params=["pair", "single"])
+@pytest.fixture(params=["single", "pair"])
 def mlp_ring(request, monkeypatch):
-    """Both ring disciplines of k_mlp_fused: one s_barrier per two weight tiles (default) and per tile (GWW_MLP_PAIR=0)."""
-    if request.param == "single":
-        monkeypatch.setenv("GWW_MLP_PAIR", "0")
+    """Both ring disciplines of k_mlp_fused: one s_barrier per weight tile (default) and per two tiles (GWW_MLP_PAIR=1)."""
+    if request.param == "pair":
+        monkeypatch.setenv("GWW_MLP_PAIR", "1")
     return request.param
 
 
