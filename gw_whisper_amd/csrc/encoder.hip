@@ -783,9 +783,12 @@ extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int b
       void* ctx = lb + sl.ctx;
       float* x_mid = (float*)(lb + sl.x_mid);
       void* z = lb + sl.z;
-      if (l == 0)
-        GWW_TRY(launch_gemm_astat(x_in(0), d, nullptr, nullptr, W.uqkv, W.cbqkv, W.wqkv_ln, nullptr, qkv, M, 3 * d, d,
-                                  EPI_BIAS, 0, s));
+      if (l == 0) {
+        // layer 0: LayerNorm kernel + plain A-stationary q/k/v GEMM (at this batch the LayerNorm-fused variant is the
+        // slower one: 292 us against 41 + 112 us at 64 segments -- it re-reads the fp32 panel per n-split)
+        GWW_TRY(launch_layernorm(x_in(0), W.ln1w, W.ln1b, d1, 1, M, d, s));
+        GWW_TRY(launch_gemm_astat(d1, d, nullptr, nullptr, nullptr, nullptr, W.wqkv, W.bqkv16, qkv, M, 3 * d, d, EPI_BIAS, 0, s));
+      }
       if (pooled && l == L - 1) {
         // only the query tile that holds token T - 1 is needed (forward and backward): the other rows of ctx / lse stay
         // zero so that the backward's row dots see finite values
@@ -922,13 +925,9 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
     const bool fused = train_fused(e->cfg);
     if (fused) {
       // the fused forward kept neither LN1(x_in) (the X operand of the q / k / v adapter gradients) nor the pre-GELU
-      // fc1 output: recompute them into the workspace (LN kernel; LayerNorm-folded A-stationary fc1 GEMM, plain bias epilogue)
+      // fc1 output: LN1 is recomputed here, fc1 inside the GELU-backward GEMM below
       GWW_TRY(launch_layernorm(x_in(l), W.ln1w, W.ln1b, base + w.h2, 1, M, d, s));
       h1 = base + w.h2;
-      if (!(pooled && l == L - 1)) {
-        GWW_TRY(launch_gemm_astat(x_mid, d, nullptr, nullptr, W.u1, W.cb1, W.w1_ln, nullptr, base + w.f1, M, F, d, EPI_BIAS, 0, s));
-        z = base + w.f1;
-      }
     }
     if (pooled && l == L - 1) {
       // ---- last layer of a pooled step: everything above the attention lives on the B last-token rows
@@ -966,7 +965,15 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
     } else {
     // fc2 / GELU / fc1 / LN2   (x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))))
     GWW_TRY(gemm_dx(dxb, d, W.w2T, dbig, F, d));
-    GWW_TRY(launch_gelu_bf16(z, dbig, dbig, ((M * F + 7) / 8) * 8, s));
+    if (fused) {
+      // recompute: LN2(x_mid) (LayerNorm kernel, into the idle dctx buffer) -> fc1 as a plain A-stationary GEMM whose
+      // epilogue applies gelu'(pre-activation) to the gradient in place: neither the pre-activation nor a separate
+      // GELU-backward pass touches HBM
+      GWW_TRY(launch_layernorm(x_mid, W.ln2w, W.ln2b, dctx, 1, M, d, s));
+      GWW_TRY(launch_gemm_astat(dctx, d, dbig, nullptr, nullptr, nullptr, W.w1, W.b1, dbig, M, F, d, EPI_DGELU, 0, s));
+    } else {
+      GWW_TRY(launch_gelu_bf16(z, dbig, dbig, ((M * F + 7) / 8) * 8, s));
+    }
     GWW_TRY(gemm_dx(dbig, F, W.w1T, dh, d, F));
     GWW_TRY(launch_ln_bwd(x_mid, W.ln2w, dh, 0, dx, 1, dxb, M, d, s));
     // out_proj / attention / QKV / LN1   (x_mid = x_in + out_proj(attn(qkv(LN1(x_in)))))

@@ -6,6 +6,7 @@
 namespace gww {
 
 enum : int { EPI_CONV1 = 4 };   // conv1: gelu(acc+bias) -> padded token-major buffer, row m + 1
+enum : int { EPI_DGELU = 5 };   // training backward (gemm_astat.hip): C = mul * gelu'(acc + bias), mul bf16 [M, N] (may alias C)
 
 template <int EPI, bool BF16OUT>
 __device__ __forceinline__ void epilogue_store4(f32x4 acc, long m, int n, long M, int N,

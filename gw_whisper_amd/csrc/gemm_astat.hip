@@ -172,34 +172,43 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* Aany, 
     // Lane (crow, cchunk) owns float4 #cchunk of a 32-float half slice of rows 8 i + crow.
     const float* X = reinterpret_cast<const float*>(Aany);
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, cshift[4];
-    const unsigned short* D = delta;
+    // lda == K here (checked by the launcher): one base pointer per row group, every other offset is an immediate
+    // (48 / 64 separate 64-bit addresses were what spilled in this prologue)
+    const float* xrow[4];
+    const unsigned short* drow[4];
+    float* orow_[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xrow[i] = X + grow[i] * K + 4 * cchunk;
+      drow[i] = delta + grow[i] * K + 4 * cchunk;
+      orow_[i] = x_out + grow[i] * K + 4 * cchunk;
+    }
 #pragma unroll
     for (int S = 0; S < KT; ++S) {
-      // one k-tile (two 32-float half slices) per group: all 8 (+8) loads are issued back to back
-      // (branch-free: HAS_DELTA is a template flag), then consumed
-      __builtin_amdgcn_sched_barrier(0);
-      float4 xv[2][4];
-      u32x2 dv[2][4];
+      // one 32-float half slice of a k-tile per group: 4 (+4) loads issued back to back (branch-free: HAS_DELTA is a
+      // template flag), then consumed.  (Whole k-tiles -- 8 + 8 loads, 48 registers in flight beside the growing A
+      // panel -- pushed the LayerNorm variants past 256 registers: 42 - 153 spilled VGPRs, some reloaded in the main
+      // loop; with two waves per SIMD the extra round trips hide behind the other wave.)
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
+      for (int h2 = 0; h2 < 2; ++h2) {
+        __builtin_amdgcn_sched_barrier(0);
+        float4 xv[4];
+        u32x2 dv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const long off = grow[i] * lda + 64 * S + 32 * h2 + 4 * cchunk;
-          xv[h2][i] = *reinterpret_cast<const float4*>(X + off);
-          if constexpr (HAS_DELTA) dv[h2][i] = *reinterpret_cast<const u32x2*>(D + off);
+          xv[i] = *reinterpret_cast<const float4*>(xrow[i] + 64 * S + 32 * h2);
+          if constexpr (HAS_DELTA) dv[i] = *reinterpret_cast<const u32x2*>(drow[i] + 64 * S + 32 * h2);
         }
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float4 v = xv[h2][i];
+          float4 v = xv[i];
           if constexpr (HAS_DELTA) {
-            v.x += bf2f((unsigned short)(dv[h2][i][0] & 0xffff));
-            v.y += bf2f((unsigned short)(dv[h2][i][0] >> 16));
-            v.z += bf2f((unsigned short)(dv[h2][i][1] & 0xffff));
-            v.w += bf2f((unsigned short)(dv[h2][i][1] >> 16));
+            v.x += bf2f((unsigned short)(dv[i][0] & 0xffff));
+            v.y += bf2f((unsigned short)(dv[i][0] >> 16));
+            v.z += bf2f((unsigned short)(dv[i][1] & 0xffff));
+            v.w += bf2f((unsigned short)(dv[i][1] >> 16));
             // x_new written back (rows past M are clamped duplicates of row M-1: same value, benign)
-            *reinterpret_cast<float4*>(x_out + grow[i] * lda + 64 * S + 32 * h2 + 4 * cchunk) = v;
+            *reinterpret_cast<float4*>(orow_[i] + 64 * S + 32 * h2) = v;
           }
           if (S == 0 && h2 == 0) {   // shift = mean of the row's first 32 values (any shift is exact algebra)
             float t = (v.x + v.y) + (v.z + v.w);
@@ -214,6 +223,7 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* Aany, 
           u32x2 o = {pack2bf(v.x, v.y), pack2bf(v.z, v.w)};
           *reinterpret_cast<u32x2*>(slice + (8 * i + crow) * AS_SLICE_STRIDE + h2 * 64 + cchunk * 8) = o;
         }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         u32x4 u = *reinterpret_cast<const u32x4*>(slice + r * AS_SLICE_STRIDE + (4 * hh + j) * 16);
@@ -308,6 +318,10 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* Aany, 
           if constexpr (EPI == EPI_GELU || EPI == EPI_CONV1) {
             v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3);
           }
+          if constexpr (EPI == EPI_DGELU) {   // gelu'(z) = Phi(z) + z phi(z)  (train_ops.hip::k_gelu_bf16<true>)
+            auto dg = [](float z) { return 0.5f * (1.0f + erff(z * 0.70710678f)) + z * 0.3989422804f * __expf(-0.5f * z * z); };
+            v0 = dg(v0); v1 = dg(v1); v2 = dg(v2); v3 = dg(v3);
+          }
           u32x2 o = {pack2bf(v0, v1), pack2bf(v2, v3)};
           *reinterpret_cast<u32x2*>(slice + r * AS_SLICE_STRIDE + (32 * tt + 8 * c + 4 * hh) * 2) = o;
           acc[t][4 * c] = 0.f; acc[t][4 * c + 1] = 0.f; acc[t][4 * c + 2] = 0.f; acc[t][4 * c + 3] = 0.f;
@@ -327,6 +341,14 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* Aany, 
         // writes 1 KiB of contiguous memory and the consumer reads whole [rows][64] tiles
         unsigned short* dst = c_panel_rows ? C + ((long)(2 * nn + half) * c_panel_rows + orow) * 64 + 8 * cchunk
                                            : C + orow * N + nn * AS_BN + 64 * half + 8 * cchunk;
+        if constexpr (EPI == EPI_DGELU) {   // times the incoming gradient (whole-line loads of the same [M, N] layout)
+          const long mrow = orow < M ? orow : M - 1;
+          const u32x4 g = *reinterpret_cast<const u32x4*>(delta + mrow * N + nn * AS_BN + 64 * half + 8 * cchunk);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            u[q] = pack2bf(bf2f((unsigned short)(u[q] & 0xffff)) * bf2f((unsigned short)(g[q] & 0xffff)),
+                           bf2f((unsigned short)(u[q] >> 16)) * bf2f((unsigned short)(g[q] >> 16)));
+        }
         *reinterpret_cast<u32x4*>(dst) = u;
       }
     }
@@ -359,7 +381,7 @@ int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, 
   const long panels = cdiv(M, AS_BM);
   const int tiles_n = N / AS_BN;
   // with a delta every workgroup of a row panel rewrites the same x_new values: keep the split minimal
-  int n_split = delta ? 1 : as_pick_split(panels, tiles_n);
+  int n_split = (delta && epi != EPI_DGELU) ? 1 : as_pick_split(panels, tiles_n);
   while (cdiv(tiles_n, n_split) > 12) n_split *= 2;   // lds_bias / lds_u hold 1536 columns
   int valid_rows = 0;
   if (epi == EPI_CONV1) {
@@ -370,9 +392,11 @@ int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, 
   }
   const bool ln = ln_u != nullptr;
   GWW_REQUIRE(!ln || ln_cb, "gemm_astat: ln_u and ln_cb go together");
-  GWW_REQUIRE(ln || (!delta && !x_out), "gemm_astat: delta / x_out need the LayerNorm prologue");
+  GWW_REQUIRE(ln || epi == EPI_DGELU || (!delta && !x_out), "gemm_astat: delta / x_out need the LayerNorm prologue");
+  GWW_REQUIRE(epi != EPI_DGELU || (delta && !x_out && !ln && !c_panel_rows), "gemm_astat: the gelu-backward epilogue takes the "
+              "incoming gradient through `delta` (plain bf16 A operand, row-major C)");
   GWW_REQUIRE(!ln || lda == K, "gemm_astat: fused LayerNorm needs lda == K");
-  GWW_REQUIRE((delta == nullptr) == (x_out == nullptr), "gemm_astat: delta and x_out go together");
+  GWW_REQUIRE(epi == EPI_DGELU || (delta == nullptr) == (x_out == nullptr), "gemm_astat: delta and x_out go together");
   GWW_REQUIRE(!x_out || (const void*)x_out != A, "gemm_astat: x_out must not alias the input stream");
   dim3 grid((unsigned)(panels * n_split)), block(AS_THREADS);
 #define GWW_AS_LAUNCH(E, AM, KT, HD)                                                                        \
@@ -398,6 +422,7 @@ int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, 
     if (epi == EPI_BIAS) GWW_AS_K(EPI_BIAS, AMODE_BF16);
     else if (epi == EPI_GELU) GWW_AS_K(EPI_GELU, AMODE_BF16);
     else if (epi == EPI_CONV1) GWW_AS_K(EPI_CONV1, AMODE_BF16);
+    else if (epi == EPI_DGELU) GWW_AS_K2(EPI_DGELU, AMODE_BF16, false);
     else return fail(GWW_ERR_ARG, "gemm_astat: unsupported epilogue %d", epi);
   }
 #undef GWW_AS_K

@@ -256,3 +256,63 @@ def test_slicer_whitens_raw_strain_like_the_reference_process(T, gww):
     w = sl.windows(3, 5).cpu().numpy()
     np.testing.assert_allclose(w[1], ref[:, 4 * 204:4 * 204 + 2048], atol=2e-3 * 32)
     assert sl.times_host(0, 1)[0] == 1000.125 + 0.6
+
+
+def test_config4_q_front_end_feeds_the_22_class_head(T, gww):
+    """BASELINE config 4 as BASELINE.json words it -- Glitch 22-class head (Glitch_classification/src/model.py:10-38),
+    whisper-base, Q-TRANSFORM front end: QTransformAdapter (one detector, 128 x 128 Q-scan: MLGWSC-1/train.py:78-154) ->
+    encoder -> models.glitch_classifier.  Against the oracle pipeline (oracle Q-scan -> the same CNN in fp64 on the CPU
+    -> adaptive pool / affine / FiLM -> oracle whisper-base -> oracle head): logits within 5e-3 (the Q-scan itself is
+    parity-unpinned: DESIGN.md section 2), argmax labels exact where the oracle's top-2 margin exceeds 1e-2."""
+    from gw_whisper_amd import synth
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    from gw_whisper_amd.models import glitch_classifier
+    from gw_whisper_amd.qscan import QTransformAdapter
+    from oracle import encoder as oenc, heads as oheads, qscan as oq
+    T.manual_seed(5)
+    d, L, H, F = synth.ENCODER_SIZES["base"]
+    sd = synth.encoder_state_dict(d, L, H, F, seed=4)
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig.named("base"), precision="bf16")
+    for p in enc.parameters():
+        p.requires_grad = False
+    adapter = QTransformAdapter.train_variant(n_detectors=1).cuda().eval()
+    with T.no_grad():
+        adapter.scale.fill_(0.05)
+        adapter.bias.fill_(-0.3)
+        adapter.film_gamma.fill_(1.2)
+        adapter.film_beta.fill_(0.1)
+
+    class GlitchOnQ(T.nn.Module):          # the reference's model class on a front end that emits [B, 80, 3000]
+        def __init__(self):
+            super().__init__()
+            self.adapter, self.net = adapter, glitch_classifier(enc, num_classes=22)
+        def forward(self, x):
+            return self.net(self.adapter(x[:, None, :])[:, 0])
+    model = GlitchOnQ()
+    head = synth.head_state_dict([d, 512, 256, 128, 22], seed=769, sequential_stride=3)
+    model.net.classifier.load_state_dict({k: T.from_numpy(v) for k, v in head.items()})
+    model = model.cuda().eval()
+    n = 4
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((n, 2048))
+    t = np.arange(2048) / 2048.0
+    for i in range(n):       # glitch-like bursts of different loudness / frequency
+        x[i] += (3.0 + 6.0 * i) * np.sin(2 * np.pi * (50 + 60 * i + 200 * t) * t) * np.exp(-((t - 0.3 - 0.1 * i) / 0.05) ** 2)
+    with T.no_grad():
+        logits = model(T.from_numpy(x.astype(np.float32)).cuda()).cpu().numpy()
+    assert logits.shape == (n, 22) and np.isfinite(logits).all()
+    # oracle
+    q = oq.qscan(x, spectrogram_shape=(128, 128), qrange=(4, 128))
+    cnn = T.nn.Sequential(*[m for m in adapter.freq_adapter]).cpu().double()
+    with T.no_grad():
+        y = T.nn.functional.adaptive_avg_pool2d(cnn(T.from_numpy(q)[:, None]), (80, 3000))[:, 0]
+        y = (0.05 * y - 0.3) * 1.2 + 0.1
+    hidden = oenc.encoder_forward(sd, y.numpy().astype(np.float32), oenc.EncCfg(d, L, H, F), dtype=np.float32)
+    ref = oheads.mlp(hidden[:, -1, :].astype(np.float64), head)
+    err = np.abs(logits - ref).max()
+    srt = np.sort(ref, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    print(f"config 4 (Q front end, whisper-base, 22 classes): max |logit - oracle| {err:.3e}, top-2 margins {margin.round(4)}")
+    assert err < 5e-3
+    sure = margin > 1e-2
+    np.testing.assert_array_equal(logits.argmax(1)[sure], ref.argmax(1)[sure])
