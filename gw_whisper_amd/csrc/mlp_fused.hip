@@ -45,6 +45,11 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #ifndef GWW_MF_AHEAD
 #define GWW_MF_AHEAD 6
 #endif
+#ifndef GWW_MF_NORM
+#define GWW_MF_NORM 1   // 1: the A operand is normalised once per panel, a^ = bf16((a - mean') rstd), so the fc1 / q,k,v outputs need
+                        // only + cb (0: round 1's per-value LayerNorm algebra rstd (acc - mean' u) + cb: two more VALU
+                        // instructions and an LDS read of u per activation value -- the GELU path is what bounds the main loop)
+#endif
 constexpr int MF_AHEAD = GWW_MF_AHEAD;   // tiles in flight ahead of the one being computed
 // Ring slots.  PAIR = false: AHEAD + 1 slots, one s_barrier per 16-KiB tile.  PAIR = true: AHEAD + 2 slots and ONE
 // barrier per TWO tiles (at the even ones): the wait in front of it leaves 3 tiles in flight, so tiles it, it + 1 and
@@ -260,6 +265,21 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     row_mean = stat[32 + r];
     asm volatile("" : "+v"(row_rstd), "+v"(row_mean)::"memory");
   }
+#if GWW_MF_NORM
+  // normalise the panel in place (every lane owns the fragments of ITS row r): 96 registers x 5 instructions, once per panel
+  auto normalise_af = [&]() {
+    const float nm = -row_mean * row_rstd;
+#pragma unroll
+    for (int i = 0; i < MF_KT * 4; ++i) {
+      u32x4 w = __builtin_bit_cast(u32x4, af[i]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        w[q] = pack2bf(fmaf(bf2f((unsigned short)(w[q] & 0xffff)), row_rstd, nm), fmaf(bf2f((unsigned short)(w[q] >> 16)), row_rstd, nm));
+      af[i] = __builtin_bit_cast(bf16x8, w);
+    }
+  };
+  normalise_af();
+#endif
   mf_wait_vmcnt<0>();   // every ordinary load / store is retired before the ring starts counting
   MSTAMP(0);
 #pragma unroll
@@ -292,14 +312,20 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   auto act_begin = [&](int slot, int c, int p) {
     if (GWW_MF_EXP & 2) return;
     const int nl = 128 * c + 32 * (p >> 2) + 8 * (p & 3) + 4 * hh;
+#if !GWW_MF_NORM
     const float4 uv = *reinterpret_cast<const float4*>(lds_u + nl);
-    const float4 bv = *reinterpret_cast<const float4*>(lds_cb + nl);
     a_u[slot][0] = uv.x; a_u[slot][1] = uv.y; a_u[slot][2] = uv.z; a_u[slot][3] = uv.w;
+#endif
+    const float4 bv = *reinterpret_cast<const float4*>(lds_cb + nl);
     a_b[slot][0] = bv.x; a_b[slot][1] = bv.y; a_b[slot][2] = bv.z; a_b[slot][3] = bv.w;
   };
   auto act_val = [&](int slot, int p, int e) {
     if (GWW_MF_EXP & 2) return;
+#if GWW_MF_NORM
+    a_v[slot][e] = gelu_sig(sacc[p >> 2][4 * (p & 3) + e] + a_b[slot][e]);
+#else
     a_v[slot][e] = gelu_sig(fmaf(row_rstd, fmaf(-row_mean, a_u[slot][e], sacc[p >> 2][4 * (p & 3) + e]), a_b[slot][e]));
+#endif
   };
   auto act_end = [&](int slot, int p) {
     if (GWW_MF_EXP & 2) return;
@@ -614,6 +640,9 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       row_mean = stat[32 + r];
       asm volatile("" : "+v"(row_rstd), "+v"(row_mean)::"memory");
     }
+#if GWW_MF_NORM
+    normalise_af();
+#endif
     // u / cb of the QKV panel replace fc1's (every wave is past its last GELU piece: those end three tiles, i.e.
     // three barriers, before the loop exit)
     for (int i = tid; i < NQ; i += MF_THREADS) {
@@ -691,12 +720,17 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #pragma unroll
           for (int cc = 0; cc < 4; ++cc) {
             const int nl = 128 * nt + 32 * t + 8 * cc + 4 * hh;
-            const float4 uv = *reinterpret_cast<const float4*>(lds_u + nl);
             const float4 bv = *reinterpret_cast<const float4*>(lds_cb + nl);
+#if GWW_MF_NORM
+            const float v0 = acc[t][4 * cc] + bv.x, v1 = acc[t][4 * cc + 1] + bv.y;
+            const float v2 = acc[t][4 * cc + 2] + bv.z, v3 = acc[t][4 * cc + 3] + bv.w;
+#else
+            const float4 uv = *reinterpret_cast<const float4*>(lds_u + nl);
             const float v0 = fmaf(row_rstd, fmaf(-row_mean, uv.x, acc[t][4 * cc]), bv.x);
             const float v1 = fmaf(row_rstd, fmaf(-row_mean, uv.y, acc[t][4 * cc + 1]), bv.y);
             const float v2 = fmaf(row_rstd, fmaf(-row_mean, uv.z, acc[t][4 * cc + 2]), bv.z);
             const float v3 = fmaf(row_rstd, fmaf(-row_mean, uv.w, acc[t][4 * cc + 3]), bv.w);
+#endif
             u32x2 o = {pack2bf(v0, v1), pack2bf(v2, v3)};
             *reinterpret_cast<u32x2*>(slice + r * MF_SLICE_STRIDE + (32 * tt + 8 * cc + 4 * hh) * 2) = o;
           }
