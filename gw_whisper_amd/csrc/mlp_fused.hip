@@ -45,6 +45,9 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #ifndef GWW_MF_AHEAD
 #define GWW_MF_AHEAD 6
 #endif
+#ifndef GWW_MF_SCHED
+#define GWW_MF_SCHED 1  // 1: GELU instructions placed by hand into the MFMA gaps (gelu_slice); 0: round 1's scheduler hints
+#endif
 #ifndef GWW_MF_NORM
 #define GWW_MF_NORM 1   // 1: the A operand is normalised once per panel, a^ = bf16((a - mean') rstd), so the fc1 / q,k,v outputs need
                         // only + cb (0: round 1's per-value LayerNorm algebra rstd (acc - mean' u) + cb: two more VALU
@@ -342,6 +345,49 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     act_end(slot, p);
   };
 
+  // ---- GELU as a stream of single instructions placed BY HAND into the MFMA gaps (GWW_MF_SCHED=1, default).
+  // hipcc ignores the sched_group_barrier hints for this dependent chain: it emitted the ~30 instructions of a step's
+  // values (+ the DMA issue) as ONE lump behind the first MFMA of the step and left 1-2 instructions in the other three
+  // gaps -- the matrix pipe idled ~90 of every 216 cycles (ISA of round 1; a build without the GELU ran 37 % faster).
+  // One wave per SIMD hides about five single-issue instructions per v_mfma_f32_32x32x16 gap, so the 16 values x 12
+  // operations of an S index are cut into 48 slices of 4 -- a phase has 3 tiles x 16 MFMAs = 48 gaps: gap g carries
+  // operations 2 j, 2 j + 1 (j = g % 6) of values 2 k and 2 k + 1 (k = g / 6), interleaved a b a b (one independent
+  // instruction between dependent ones), and a sched_barrier(0) after every gap pins the placement.
+  float g_t[2] = {0.f, 0.f}, g_w[2] = {0.f, 0.f}, g_q[2] = {0.f, 0.f};
+  float2 g_b = {0.f, 0.f};
+#define MF_FENCE(ACC) asm volatile("" : "+a"(ACC), "+v"(g_t[0]), "+v"(g_t[1]), "+v"(g_w[0]), "+v"(g_w[1]), "+v"(g_q[0]), "+v"(g_q[1]))
+  auto gelu_slice = [&](int t, int cpair, int g) {   // every argument is a compile-time constant after unrolling
+    if (GWW_MF_EXP & 2) return;
+    const int k = g / 6, j = g % 6;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int op = 2 * j + h;
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const int v = 2 * k + sl;
+        float& T_ = g_t[sl];
+        float& W_ = g_w[sl];
+        float& Q_ = g_q[sl];
+        if (op == 0) {
+          if (sl == 0) g_b = *reinterpret_cast<const float2*>(lds_cb + 128 * cpair + 32 * t + 8 * (v >> 2) + 4 * hh + (v & 3));
+          T_ = sacc[t][v] + (sl == 0 ? g_b.x : g_b.y);
+        } else if (op == 1) W_ = T_ * T_;
+        else if (op == 2) asm("v_min_f32 %0, 0x42800000, %0" : "+v"(W_));   // min(x^2, 64): plain fminf adds a canonicalising v_max behind the fence
+        else if (op == 3) Q_ = fmaf(W_, 0.0010148164f, -0.1067791331f);
+        else if (op == 4) Q_ = fmaf(W_, Q_, -2.3011178f);
+        else if (op == 5) W_ = T_ * Q_;
+        else if (op == 6) W_ = __builtin_amdgcn_exp2f(W_);
+        else if (op == 7) W_ = 1.0f + W_;
+        else if (op == 8) W_ = __builtin_amdgcn_rcpf(W_);
+        else if (op == 9) T_ = T_ * W_;
+        else if (op == 10 && sl == 1) {
+          const int cc = k >> 1;
+          pf[t][cc >> 1][2 * (cc & 1) + (k & 1)] = pack2bf(g_t[0], g_t[1]);
+        }
+      }
+    }
+  };
+
   // tile 0 landed (younger tiles may still be in flight)
   mf_wait_vmcnt<MF_GL*(MF_AHEAD - 1)>();
   __builtin_amdgcn_s_barrier();
@@ -398,7 +444,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       const int v0 = (16 * j12) / 12, v1 = (16 * (j12 + 1)) / 12;
       __builtin_amdgcn_sched_barrier(0);
       if (!(GWW_MF_EXP & 1)) issue_piece(dma_tile, dma_stage, sub);
-      if (RIDE_T >= 0) {
+      if (!GWW_MF_SCHED && RIDE_T >= 0) {
 #pragma unroll
         for (int v = v0; v < v1; ++v) {
           const int p = 4 * RIDE_T + (v >> 2), e = v & 3;
@@ -427,13 +473,28 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           oacc[4 * IDX3 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
               cur[u], __builtin_bit_cast(bf16x8, pf[2 * PAR + (sub >> 1)][sub & 1]), oacc[4 * IDX3 + u], 0, 0, 0);
         }
+        // hipcc moves MFMAs across sched_barrier(0) relative to the (independent) GELU chain; empty volatile asm statements
+        // that name BOTH the adjacent MFMA's accumulator and the GELU state pin the order: MFMA u | fence | fragment read +
+        // four GELU instructions | fence | MFMA u + 1
+        if (GWW_MF_SCHED && RIDE_T >= 0) {
+          if (KIND == 0) MF_FENCE(sacc[2 * PAR + (u & 1)]);
+          else MF_FENCE(oacc[4 * IDX3 + u]);
+        }
         if (!(GWW_MF_EXP & 4)) {
           int off;
           if (sub == 3) off = first_off(next_kind, u);
           else off = KIND == 0 ? (u & 1) * 8192 + off1[2 * (sub + 1) + (u >> 1)] : u * 4096 + off2[sub + 1];
           nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + off);
         }
+        if (GWW_MF_SCHED && RIDE_T >= 0) {
+          gelu_slice(RIDE_T, ride_cpair, 16 * IDX3 + 4 * sub + u);
+          if (!(sub == 3 && u == 3)) {   // tie the slice in front of the next MFMA of this tile
+            if (KIND == 0) MF_FENCE(sacc[2 * PAR + ((u + 1) & 1)]);
+            else MF_FENCE(oacc[4 * IDX3 + ((u + 1) & 3)]);
+          }
+        }
       }
+      if (GWW_MF_SCHED) continue;
       // pipeline of the step: MFMA, fragment read, a slice of the VALU work -- four times
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
