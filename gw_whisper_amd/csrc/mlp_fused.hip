@@ -355,7 +355,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   // instruction between dependent ones), and a sched_barrier(0) after every gap pins the placement.
   float g_t[2] = {0.f, 0.f}, g_w[2] = {0.f, 0.f}, g_q[2] = {0.f, 0.f};
   float2 g_b = {0.f, 0.f};
-#define MF_FENCE(ACC) asm volatile("" : "+a"(ACC), "+v"(g_t[0]), "+v"(g_t[1]), "+v"(g_w[0]), "+v"(g_w[1]), "+v"(g_q[0]), "+v"(g_q[1]))
+#define MF_FENCE(FRAG) asm volatile("" : "+v"(FRAG), "+v"(g_t[0]), "+v"(g_t[1]), "+v"(g_w[0]), "+v"(g_w[1]), "+v"(g_q[0]), "+v"(g_q[1]))
   auto gelu_slice = [&](int t, int cpair, int g) {   // every argument is a compile-time constant after unrolling
     if (GWW_MF_EXP & 2) return;
     const int k = g / 6, j = g % 6;
@@ -474,12 +474,11 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
               cur[u], __builtin_bit_cast(bf16x8, pf[2 * PAR + (sub >> 1)][sub & 1]), oacc[4 * IDX3 + u], 0, 0, 0);
         }
         // hipcc moves MFMAs across sched_barrier(0) relative to the (independent) GELU chain; empty volatile asm statements
-        // that name BOTH the adjacent MFMA's accumulator and the GELU state pin the order: MFMA u | fence | fragment read +
-        // four GELU instructions | fence | MFMA u + 1
-        if (GWW_MF_SCHED && RIDE_T >= 0) {
-          if (KIND == 0) MF_FENCE(sacc[2 * PAR + (u & 1)]);
-          else MF_FENCE(oacc[4 * IDX3 + u]);
-        }
+        // that name BOTH a W fragment of the adjacent MFMA and the GELU state pin the order: MFMA u | fence (clobbers the
+        // fragment MFMA u has just read: write-after-read) | fragment read + four GELU instructions | fence (defines the
+        // fragment MFMA u + 1 reads) | MFMA u + 1.  (Naming the ACCUMULATOR instead makes hipcc wait out the MFMA's
+        // result latency in front of every fence: measured 0.2 ms slower per launch.)
+        if (GWW_MF_SCHED && RIDE_T >= 0) MF_FENCE(cur[u]);
         if (!(GWW_MF_EXP & 4)) {
           int off;
           if (sub == 3) off = first_off(next_kind, u);
@@ -488,10 +487,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         }
         if (GWW_MF_SCHED && RIDE_T >= 0) {
           gelu_slice(RIDE_T, ride_cpair, 16 * IDX3 + 4 * sub + u);
-          if (!(sub == 3 && u == 3)) {   // tie the slice in front of the next MFMA of this tile
-            if (KIND == 0) MF_FENCE(sacc[2 * PAR + ((u + 1) & 1)]);
-            else MF_FENCE(oacc[4 * IDX3 + ((u + 1) & 3)]);
-          }
+          if (u < 3) MF_FENCE(cur[u + 1]);   // tie the slice in front of the next MFMA of this step
+          else if (sub < 3) MF_FENCE(nxt[0]);  // ... of the next step (its fragments are this step's `nxt`)
         }
       }
       if (GWW_MF_SCHED) continue;
