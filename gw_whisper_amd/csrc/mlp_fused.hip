@@ -46,7 +46,13 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #define GWW_MF_AHEAD 6
 #endif
 #ifndef GWW_MF_SCHED
-#define GWW_MF_SCHED 1  // 1: GELU instructions placed by hand into the MFMA gaps (gelu_slice); 0: round 1's scheduler hints
+#define GWW_MF_SCHED 0  // 1: GELU instructions placed by hand into the MFMA gaps (gelu_slice + order fences: every gap then holds
+                        // one fragment read + four GELU instructions, checked in the ISA); 0: round 1's scheduler hints, which
+                        // hipcc turns into one ~30-instruction lump per four MFMAs.  MEASURED EQUAL (1.36 / 1.36 ms plain,
+                        // 1.74 / 1.72 ms with q/k/v, tools/mlp_exp.py, one process per build on one box): the kernel's time
+                        // follows the NUMBER of instructions it executes, not their placement -- the chip holds ~1.35 GHz
+                        // under this kernel (power), so a build without the GELU is 37 % faster, without the fragment reads
+                        // 21 %, without the DMA 6 %, wherever those instructions sit.
 #endif
 #ifndef GWW_MF_NORM
 #define GWW_MF_NORM 1   // 1: the A operand is normalised once per panel, a^ = bf16((a - mean') rstd), so the fc1 / q,k,v outputs need
