@@ -37,16 +37,19 @@ constexpr int MF_KT = MF_D / 64;           // 6 k-tiles of fc1
 constexpr int MF_OT = MF_D / 32;           // 12 output sub-tiles of fc2
 constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #ifndef GWW_MF_EXP
-#define GWW_MF_EXP 0   // diagnostic builds only: 1 = no DMA in the loop, 2 = no GELU, 4 = no fragment reads in the loop, 8 = stream folded onto its first 8 tiles
+#define GWW_MF_EXP 0   // diagnostic builds only: 1 = no DMA in the loop, 2 = no GELU, 4 = no fragment reads in the loop, 8 = stream folded onto its first 8 tiles, 16 = GELU bias not read from LDS, 32 = GELU transcendentals replaced by multiplies, 64 = no ring wait / barrier per tile
+#endif
+#ifndef GWW_MF_OLDDMA
+#define GWW_MF_OLDDMA 0   // diagnostic: round 1's eight-instruction DMA issue
 #endif
 #ifndef GWW_MF_VG
 #define GWW_MF_VG 18   // VALU instructions scheduled behind each MFMA of a step that carries a GELU piece
 #endif
 #ifndef GWW_MF_AHEAD
-#define GWW_MF_AHEAD 6
+#define GWW_MF_AHEAD 3
 #endif
 #ifndef GWW_MF_SCHED
-#define GWW_MF_SCHED 0  // 1: GELU instructions placed by hand into the MFMA gaps (gelu_slice + order fences: every gap then holds
+#define GWW_MF_SCHED 1  // 1: GELU instructions placed by hand into the MFMA gaps (gelu_slice + order fences: every gap then holds
                         // one fragment read + four GELU instructions, checked in the ISA); 0: round 1's scheduler hints, which
                         // hipcc turns into one ~30-instruction lump per four MFMAs.  MEASURED EQUAL (1.36 / 1.36 ms plain,
                         // 1.74 / 1.72 ms with q/k/v, tools/mlp_exp.py, one process per build on one box): the kernel's time
@@ -54,17 +57,22 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
                         // under this kernel (power), so a build without the GELU is 37 % faster, without the fragment reads
                         // 21 %, without the DMA 6 %, wherever those instructions sit.
 #endif
+#ifndef GWW_MF_VACC
+#define GWW_MF_VACC 1   // (with SCHED) fc1 accumulators in architectural registers, MFMAs as asm
+#endif
+#ifndef GWW_MF_AF_AGPR
+#define GWW_MF_AF_AGPR 0   // how many of the 24 A-operand fragments (4 registers each) are pinned to the accumulator file
+#endif
 #ifndef GWW_MF_NORM
 #define GWW_MF_NORM 1   // 1: the A operand is normalised once per panel, a^ = bf16((a - mean') rstd), so the fc1 / q,k,v outputs need
                         // only + cb (0: round 1's per-value LayerNorm algebra rstd (acc - mean' u) + cb: two more VALU
                         // instructions and an LDS read of u per activation value -- the GELU path is what bounds the main loop)
 #endif
+constexpr int MF_AF_AGPR = GWW_MF_AF_AGPR;
 constexpr int MF_AHEAD = GWW_MF_AHEAD;   // tiles in flight ahead of the one being computed
-// Ring slots.  PAIR = false: AHEAD + 1 slots, one s_barrier per 16-KiB tile.  PAIR = true: AHEAD + 2 slots and ONE
-// barrier per TWO tiles (at the even ones): the wait in front of it leaves 3 tiles in flight, so tiles it, it + 1 and
-// it + 2 (whose first fragments are prefetched in the last step of tile it + 1) have landed for every wave; the DMA
-// issued during tile it (it + 1) overwrites the slot of tile it - 2 (it - 1), which every wave left before that barrier.
-constexpr int MF_NST_MAX = MF_AHEAD + 2;
+// Ring: AHEAD + 1 slots of one 16-KiB tile, one s_barrier per tile.  (One barrier per two tiles with one more slot was
+// built and measured in round 2: 1.154 vs 1.159 ms plain, 1.653 vs 1.653 ms with q/k/v -- no gain, removed.)
+constexpr int MF_NST_MAX = MF_AHEAD + 1;
 constexpr int MF_TILE = 128 * 64 * 2;      // 16 KB
 constexpr int MF_GL = 16 / MF_WAVES;       // LDS-DMA pieces per thread per tile
 constexpr int MF_FMAX = 1536;              // largest ffn (cb / u staged in LDS)
@@ -77,6 +85,9 @@ constexpr int MF_LDS = MF_OFF_SLICE + MF_WAVES * MF_SLICE_BYTES;
 static_assert(MF_LDS <= 160 * 1024, "LDS budget");
 
 template <int N>
+using MF_FL = std::integral_constant<int, N>;   // flat index of a tile in the unrolled stream (its ring stage, mod 4)
+
+template <int N>
 __device__ __forceinline__ void mf_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -87,16 +98,26 @@ __device__ __forceinline__ float gelu_sig(float x) {
   const float s = fminf(x * x, 64.0f);
   float q = fmaf(s, 0.0010148164f, -0.1067791331f);     // -log2(e) * (a5 s + a3)
   q = fmaf(s, q, -2.3011178f);                          // -log2(e) * a1
+#if GWW_MF_EXP & 32   // diagnostic: the two transcendentals replaced by plain multiplies (wrong values, same count)
+  const float e = (x * q) * 0.37f;
+  return x * ((1.0f + e) * 0.91f);
+#else
   const float e = __builtin_amdgcn_exp2f(x * q);        // exp(-p(x))
   return x * __builtin_amdgcn_rcpf(1.0f + e);
+#endif
 }
 
 // ---- optional in-kernel phase stamps (diagnostic build only: -DGWW_STAMP), cycles per phase
 #ifdef GWW_STAMP
 __device__ unsigned long long g_stamp_mlp[24];
-#define MSTAMP_DECL unsigned long long _t0 = __builtin_amdgcn_s_memtime(); unsigned long long _acc[20] = {0};
+// GWW_STAMP=2: only the prologue / main loop / epilogue boundaries (stamps 0, 4, 3) -- no sched_barrier inside the main
+// loop, the kernel runs as the production build does.  Entries 21 / 22: the wave's life in s_memrealtime (100 MHz) and
+// s_memtime (shader clock) ticks: their ratio is the clock the chip actually held under this kernel.
+#define MSTAMP_DECL unsigned long long _t0 = __builtin_amdgcn_s_memtime(); unsigned long long _acc[20] = {0}; \
+  const unsigned long long _tb = _t0, _rb = __builtin_amdgcn_s_memrealtime();
 #define MSTAMP(i)                                                  \
   do {                                                             \
+    if (GWW_STAMP == 2 && (i) != 0 && (i) != 3 && (i) != 4) break; \
     __builtin_amdgcn_sched_barrier(0);                             \
     const unsigned long long _t1 = __builtin_amdgcn_s_memtime();   \
     _acc[i] += _t1 - _t0;                                          \
@@ -106,6 +127,8 @@ __device__ unsigned long long g_stamp_mlp[24];
 #define MSTAMP_FLUSH                                                                 \
   if (lane == 0) {                                                                   \
     for (int _q = 0; _q < 20; ++_q) atomicAdd(&g_stamp_mlp[_q], _acc[_q]);           \
+    atomicAdd(&g_stamp_mlp[21], __builtin_amdgcn_s_memrealtime() - _rb);             \
+    atomicAdd(&g_stamp_mlp[22], __builtin_amdgcn_s_memtime() - _tb);                 \
     atomicAdd(&g_stamp_mlp[23], 1ull);                                                \
   }
 #else
@@ -120,7 +143,7 @@ __device__ unsigned long long g_stamp_mlp[24];
 // while the output is still in registers; the 192 output-accumulator registers are free by then), whose weight
 // tiles simply continue the same stream.  The standalone LN+QKV kernel's 10 B/element HBM round trip of the
 // residual stream disappears.
-template <bool QKV, bool PAIR>
+template <bool QKV>
 __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, const unsigned short* delta, float* x_out,
                                                             const float* __restrict__ ln_u,
                                                             const float* __restrict__ ln_cb,
@@ -132,7 +155,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
                                                             unsigned short* __restrict__ q_out, int NQ,
                                                             float* x_next) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[MF_LDS];
-  constexpr int MF_NST = PAIR ? MF_AHEAD + 2 : MF_AHEAD + 1;
+  constexpr int MF_NST = MF_AHEAD + 1;
   float* lds_cb = reinterpret_cast<float*>(lds + MF_OFF_CB);
   float* lds_u = reinterpret_cast<float*>(lds + MF_OFF_U);
   float* lds_b2 = reinterpret_cast<float*>(lds + MF_OFF_B2);
@@ -152,15 +175,34 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lane_off = (unsigned)lane * 16u;
   const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr)lds;
-  auto issue_piece = [&](int tile, int stage, int j) {
-    const unsigned dst = lds_base + (unsigned)(stage * MF_TILE + (MF_GL * wave_u + j) * 1024);
+  // Piece j of a tile: the wave's four pieces are 4 contiguous KiB in the stream AND in the ring, so one SGPR address
+  // pair and one M0 value serve all four and j only enters as the instruction's immediate offset (which the hardware
+  // adds to both the global and the LDS address): three instructions per piece (round 1 recomputed source, destination
+  // and saved / restored M0 per piece: eight).  Nothing else in this kernel reads M0.
+  auto issue_piece_c = [&](int tile, int stage, auto j_c) {
+    constexpr int J = decltype(j_c)::value;
+    const unsigned dst = lds_base + (unsigned)(stage * MF_TILE + MF_GL * wave_u * 1024);
     if (GWW_MF_EXP & 8) tile &= 7;   // diagnostic: the whole stream collapses onto 128 KB (always L2-hot)
+    const unsigned short* src = Wt + ((long)tile * (MF_TILE / 2) + MF_GL * wave_u * 512);
+    const unsigned lo = lane_off;   // (a generic lambda's asm operands cannot name captures directly)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 :
+                 : "v"(lo), "s"(src), "s"(dst), "n"(J * 1024)
+                 : "memory");
+  };
+  auto issue_piece = [&](int tile, int stage, int j) {   // j is a constant after unrolling; the asm operand must be one before
+#if GWW_MF_OLDDMA
+    const unsigned dst = lds_base + (unsigned)(stage * MF_TILE + (MF_GL * wave_u + j) * 1024);
     const unsigned short* src = Wt + ((long)tile * (MF_TILE / 2) + (MF_GL * wave_u + j) * 512);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane_off), "s"(src), "s"(dst)
-                 : "memory");
+                 : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(dst) : "memory");
+#else
+    if (j == 0) issue_piece_c(tile, stage, std::integral_constant<int, 0>{});
+    else if (j == 1) issue_piece_c(tile, stage, std::integral_constant<int, 1>{});
+    else if (j == 2) issue_piece_c(tile, stage, std::integral_constant<int, 2>{});
+    else issue_piece_c(tile, stage, std::integral_constant<int, 3>{});
+#endif
   };
   auto issue = [&](int tile, int stage) {
 #pragma unroll
@@ -325,11 +367,18 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     const float4 uv = *reinterpret_cast<const float4*>(lds_u + nl);
     a_u[slot][0] = uv.x; a_u[slot][1] = uv.y; a_u[slot][2] = uv.z; a_u[slot][3] = uv.w;
 #endif
+    if (GWW_MF_EXP & 16) {   // diagnostic: no LDS read of the bias in front of the GELU chain
+      a_b[slot][0] = a_b[slot][1] = a_b[slot][2] = a_b[slot][3] = row_rstd;
+      return;
+    }
     const float4 bv = *reinterpret_cast<const float4*>(lds_cb + nl);
     a_b[slot][0] = bv.x; a_b[slot][1] = bv.y; a_b[slot][2] = bv.z; a_b[slot][3] = bv.w;
   };
   auto act_val = [&](int slot, int p, int e) {
-    if (GWW_MF_EXP & 2) return;
+    if (GWW_MF_EXP & 2) {   // diagnostic: no GELU arithmetic, the fc1 result is only rounded and packed (the fc1 MFMAs stay live)
+      a_v[slot][e] = sacc[p >> 2][4 * (p & 3) + e];
+      return;
+    }
 #if GWW_MF_NORM
     a_v[slot][e] = gelu_sig(sacc[p >> 2][4 * (p & 3) + e] + a_b[slot][e]);
 #else
@@ -337,7 +386,6 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #endif
   };
   auto act_end = [&](int slot, int p) {
-    if (GWW_MF_EXP & 2) return;
     const int t = p >> 2, cc = p & 3;
     pf[t][cc >> 1][2 * (cc & 1)] = pack2bf(a_v[slot][0], a_v[slot][1]);
     pf[t][cc >> 1][2 * (cc & 1) + 1] = pack2bf(a_v[slot][2], a_v[slot][3]);
@@ -359,25 +407,43 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   // operations of an S index are cut into 48 slices of 4 -- a phase has 3 tiles x 16 MFMAs = 48 gaps: gap g carries
   // operations 2 j, 2 j + 1 (j = g % 6) of values 2 k and 2 k + 1 (k = g / 6), interleaved a b a b (one independent
   // instruction between dependent ones), and a sched_barrier(0) after every gap pins the placement.
-  float g_t[2] = {0.f, 0.f}, g_w[2] = {0.f, 0.f}, g_q[2] = {0.f, 0.f};
-  float2 g_b = {0.f, 0.f};
-#define MF_FENCE(FRAG) asm volatile("" : "+v"(FRAG), "+v"(g_t[0]), "+v"(g_t[1]), "+v"(g_w[0]), "+v"(g_w[1]), "+v"(g_q[0]), "+v"(g_q[1]))
-  auto gelu_slice = [&](int t, int cpair, int g) {   // every argument is a compile-time constant after unrolling
+  // What one wave per SIMD hides behind a v_mfma_f32_32x32x16_bf16 was measured in isolation (tools/ubench/mfma_gap.hip,
+  // profiles/r02_mfma_gap.txt): five INDEPENDENT 4-cycle VALU instructions are free (32.8 cycles per MFMA with 4, 33.3
+  // with 5, 35 with 6), but an instruction that depends on the one issued just before it costs 8 cycles, not 4 (a chain
+  // a b a b over two values: 34.5 cycles with 4 per gap, 42 with 5, 47.5 with 6), v_exp / v_rcp cost 8 and so does every
+  // v_accvgpr_read.  Round 2's first hand placement interleaved TWO values (a b a b): every instruction paid the 8-cycle
+  // dependent price and the loop ran no faster than the compiler's lumps.  This one works on FOUR values per gap -- a gap
+  // holds the same operation on values 4 k, 4 k + 1 (pair A, operation j) and the previous operation on 4 k + 2, 4 k + 3
+  // (pair B, operation j - 1): nothing in a gap depends on anything in the same or the previous gap's tail, and a gap
+  // never carries more than two transcendentals.  A phase has 3 tiles x 16 MFMAs = 48 gaps = 4 groups of 12; the 11
+  // operations of a value (bias add, x^2, clamp, two fma, x q, exp2, + 1, rcp, x s, pack) fill gaps 0 .. 10 (A) and
+  // 1 .. 11 (B).  The four bias values of group k + 1 are read from LDS in gap 6 of group k (group 0 of the NEXT phase in
+  // gap 42: phases advance through the folded-bias vector by 32 floats, so its address is this phase's + 32).
+  float g_t[4] = {0.f, 0.f, 0.f, 0.f}, g_w[4] = {0.f, 0.f, 0.f, 0.f}, g_q[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 g_b[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#define MF_FENCE(FRAG)                                                                                                   \
+  asm volatile("" : "+v"(FRAG), "+v"(g_t[0]), "+v"(g_t[1]), "+v"(g_t[2]), "+v"(g_t[3]), "+v"(g_w[0]), "+v"(g_w[1]),     \
+               "+v"(g_w[2]), "+v"(g_w[3]), "+v"(g_q[0]), "+v"(g_q[1]), "+v"(g_q[2]), "+v"(g_q[3]))
+  auto gelu_bias_addr = [&](int t, int cpair, int k) -> const float4* {
+    return reinterpret_cast<const float4*>(lds_cb + 128 * cpair + 32 * t + 8 * k + 4 * hh);
+  };
+  auto gelu_slice = [&](int t, int cpair, int g) {   // t, g are compile-time constants after unrolling
     if (GWW_MF_EXP & 2) return;
-    const int k = g / 6, j = g % 6;
+    const int k = g / 12, j = g % 12;
+    if (j == 6) g_b[(k + 1) & 1] = *gelu_bias_addr(t, cpair, k + 1);   // k + 1 == 4: group 0 of the next phase
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int op = 2 * j + h;
+    for (int pr = 0; pr < 2; ++pr) {
+      const int op = j - pr;
+      if (op < 0 || op > 10) continue;
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
-        const int v = 2 * k + sl;
-        float& T_ = g_t[sl];
-        float& W_ = g_w[sl];
-        float& Q_ = g_q[sl];
-        if (op == 0) {
-          if (sl == 0) g_b = *reinterpret_cast<const float2*>(lds_cb + 128 * cpair + 32 * t + 8 * (v >> 2) + 4 * hh + (v & 3));
-          T_ = sacc[t][v] + (sl == 0 ? g_b.x : g_b.y);
-        } else if (op == 1) W_ = T_ * T_;
+        const int i = 2 * pr + sl, v = 4 * k + i;
+        float& T_ = g_t[i];
+        float& W_ = g_w[i];
+        float& Q_ = g_q[i];
+        const float4& bb = g_b[k & 1];
+        if (op == 0) T_ = sacc[t][v] + (i == 0 ? bb.x : (i == 1 ? bb.y : (i == 2 ? bb.z : bb.w)));
+        else if (op == 1) W_ = T_ * T_;
         else if (op == 2) asm("v_min_f32 %0, 0x42800000, %0" : "+v"(W_));   // min(x^2, 64): plain fminf adds a canonicalising v_max behind the fence
         else if (op == 3) Q_ = fmaf(W_, 0.0010148164f, -0.1067791331f);
         else if (op == 4) Q_ = fmaf(W_, Q_, -2.3011178f);
@@ -386,10 +452,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         else if (op == 7) W_ = 1.0f + W_;
         else if (op == 8) W_ = __builtin_amdgcn_rcpf(W_);
         else if (op == 9) T_ = T_ * W_;
-        else if (op == 10 && sl == 1) {
-          const int cc = k >> 1;
-          pf[t][cc >> 1][2 * (cc & 1) + (k & 1)] = pack2bf(g_t[0], g_t[1]);
-        }
+        else if (op == 10 && sl == 1) pf[t][k >> 1][2 * (k & 1) + pr] = pack2bf(g_t[2 * pr], g_t[2 * pr + 1]);
       }
     }
   };
@@ -427,12 +490,16 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   // KIND 1: fc2 tile ng with P = pf[2 PAR + ..].  ride_t >= 0: S index whose GELU values ride in this tile
   // (values v0 .. of its four pieces, 16 per S index, spread 1-1-2 over the 12 steps of a phase);
   // next_kind: kind of the tile that follows (its first fragments are prefetched in the last step).
-  auto run_tile = [&](auto kind_c, auto par_c, auto idx3_c, auto bar_c, auto ride_t_c, int ride_cpair, int next_kind) {
+  auto run_tile = [&](auto flat_c, auto kind_c, auto par_c, auto idx3_c, auto ride_t_c, int ride_cpair, int next_kind) {
     constexpr int KIND = decltype(kind_c)::value, PAR = decltype(par_c)::value, IDX3 = decltype(idx3_c)::value;
     constexpr int RIDE_T = decltype(ride_t_c)::value;
-    constexpr bool BAR = !PAIR || decltype(bar_c)::value != 0;   // PAIR: barrier at the even tiles only
-    if constexpr (BAR) {
-      mf_wait_vmcnt<PAIR ? MF_GL * 3 : MF_GL * (MF_AHEAD - 2)>();
+    // A four-stage ring makes the stage of every tile of the unrolled 12-tile body a compile-time constant (flat tile
+    // index mod 4): every fragment address is then base register + immediate (no v_or_b32 per read: 8 cycles each
+    // beside an MFMA, tools/ubench/mfma_gap.hip) and the DMA destination needs no wrap-around arithmetic.
+    constexpr int ST = MF_NST == 4 ? (decltype(flat_c)::value & 3) : -1;
+    if (ST >= 0) stage = ST;
+    if constexpr (!(GWW_MF_EXP & 64)) {   // (64: diagnostic, no ring wait / barrier -- only meaningful together with 1)
+      mf_wait_vmcnt<MF_GL * (MF_AHEAD - 2)>();
       __builtin_amdgcn_s_barrier();
     }
     MSTAMP(1);
@@ -466,7 +533,21 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           const int tl = u & 1;
           const int ks = 2 * sub + (u >> 1);                       // k-step of the tile, 0 .. 7
           const int afi = 4 * (2 * IDX3 + (ks >> 2)) + (ks & 3);   // af[4 S + j]
-          if (IDX3 == 0 && ks == 0) {
+          if (GWW_MF_SCHED && GWW_MF_VACC) {
+            // fc1 accumulates in ARCHITECTURAL registers (asm: hipcc gives a builtin MFMA's result to the accumulator file
+            // and then copies all 16 values out with v_accvgpr_read_b32 for the GELU -- 8 cycles each beside an MFMA,
+            // tools/ubench/mfma_gap.hip).  The GELU reads S two or more MFMAs after the last one that wrote it (the
+            // slices are pinned into their gaps), which covers the MFMA-write -> VALU-read interval hipcc cannot see here.
+            f32x16& acc = sacc[2 * PAR + tl];
+            const bool first = IDX3 == 0 && ks == 0;
+            if (afi < MF_AF_AGPR) {
+              if (first) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(cur[u]), "a"(af[afi]));
+              else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(cur[u]), "a"(af[afi]));
+            } else {
+              if (first) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(cur[u]), "v"(af[afi]));
+              else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(cur[u]), "v"(af[afi]));
+            }
+          } else if (IDX3 == 0 && ks == 0) {
             f32x16 z;
 #pragma unroll
             for (int j = 0; j < 16; ++j) z[j] = 0.f;
@@ -484,7 +565,13 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         // fragment MFMA u has just read: write-after-read) | fragment read + four GELU instructions | fence (defines the
         // fragment MFMA u + 1 reads) | MFMA u + 1.  (Naming the ACCUMULATOR instead makes hipcc wait out the MFMA's
         // result latency in front of every fence: measured 0.2 ms slower per launch.)
-        if (GWW_MF_SCHED && RIDE_T >= 0) MF_FENCE(cur[u]);
+        if (GWW_MF_SCHED && RIDE_T >= 0) {
+          MF_FENCE(cur[u]);
+          // the wait for the NEXT MFMA's fragment lands here, in front of the slice: the VALU instructions of the slice
+          // then fill the wait state hipcc otherwise pads with an s_nop between an s_waitcnt and the MFMA
+          if (u < 3) asm volatile("" : "+v"(cur[u + 1]));
+          else if (sub < 3) asm volatile("" : "+v"(nxt[0]));
+        }
         if (!(GWW_MF_EXP & 4)) {
           int off;
           if (sub == 3) off = first_off(next_kind, u);
@@ -524,42 +611,44 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   using IM = std::integral_constant<int, -1>;
 
   // G1(0): no GELU to carry yet; its first half is then computed in the open (once per 128 rows)
-  run_tile(I0{}, I0{}, I0{}, I1{}, IM{}, 0, 0);
-  run_tile(I0{}, I0{}, I1{}, I0{}, IM{}, 0, 0);
-  run_tile(I0{}, I0{}, I2{}, I1{}, IM{}, 0, 0);
+  run_tile(MF_FL<0>{}, I0{}, I0{}, I0{}, IM{}, 0, 0);
+  run_tile(MF_FL<1>{}, I0{}, I0{}, I1{}, IM{}, 0, 0);
+  run_tile(MF_FL<2>{}, I0{}, I0{}, I2{}, IM{}, 0, 0);
   act_piece(0, 0, 0); act_piece(0, 0, 1); act_piece(0, 0, 2); act_piece(0, 0, 3);
+  if (GWW_MF_SCHED) g_b[0] = *gelu_bias_addr(1, 0, 0);   // group 0 of the first riding phase (S index 1 of chunk pair 0)
   int b = 0;
   for (; b + 2 < nck; b += 2) {
     // ---- block b (parity 0): G1(b + 1) -> S[2..3] carrying the second half of GELU(b) (S[1]);
     //      G2(b) with pf[0..1] carrying the first half of GELU(b + 1) (S[2])
-    run_tile(I0{}, I1{}, I0{}, I0{}, I1{}, b >> 1, 0);
-    run_tile(I0{}, I1{}, I1{}, I1{}, I1{}, b >> 1, 0);
-    run_tile(I0{}, I1{}, I2{}, I0{}, I1{}, b >> 1, 1);
-    run_tile(I1{}, I0{}, I0{}, I1{}, I2{}, b >> 1, 1);
-    run_tile(I1{}, I0{}, I1{}, I0{}, I2{}, b >> 1, 1);
-    run_tile(I1{}, I0{}, I2{}, I1{}, I2{}, b >> 1, 0);
+    run_tile(MF_FL<3>{}, I0{}, I1{}, I0{}, I1{}, b >> 1, 0);
+    run_tile(MF_FL<4>{}, I0{}, I1{}, I1{}, I1{}, b >> 1, 0);
+    run_tile(MF_FL<5>{}, I0{}, I1{}, I2{}, I1{}, b >> 1, 1);
+    run_tile(MF_FL<6>{}, I1{}, I0{}, I0{}, I2{}, b >> 1, 1);
+    run_tile(MF_FL<7>{}, I1{}, I0{}, I1{}, I2{}, b >> 1, 1);
+    run_tile(MF_FL<8>{}, I1{}, I0{}, I2{}, I2{}, b >> 1, 0);
     // ---- block b + 1 (parity 1): G1(b + 2) -> S[0..1] carrying the second half of GELU(b + 1) (S[3]);
     //      G2(b + 1) with pf[2..3] carrying the first half of GELU(b + 2) (S[0])
-    run_tile(I0{}, I0{}, I0{}, I0{}, I3{}, b >> 1, 0);
-    run_tile(I0{}, I0{}, I1{}, I1{}, I3{}, b >> 1, 0);
-    run_tile(I0{}, I0{}, I2{}, I0{}, I3{}, b >> 1, 1);
-    run_tile(I1{}, I1{}, I0{}, I1{}, I0{}, (b >> 1) + 1, 1);
-    run_tile(I1{}, I1{}, I1{}, I0{}, I0{}, (b >> 1) + 1, 1);
-    run_tile(I1{}, I1{}, I2{}, I1{}, I0{}, (b >> 1) + 1, 0);
+    run_tile(MF_FL<9>{}, I0{}, I0{}, I0{}, I3{}, b >> 1, 0);
+    run_tile(MF_FL<10>{}, I0{}, I0{}, I1{}, I3{}, b >> 1, 0);
+    run_tile(MF_FL<11>{}, I0{}, I0{}, I2{}, I3{}, b >> 1, 1);
+    run_tile(MF_FL<12>{}, I1{}, I1{}, I0{}, I0{}, (b >> 1) + 1, 1);
+    run_tile(MF_FL<13>{}, I1{}, I1{}, I1{}, I0{}, (b >> 1) + 1, 1);
+    run_tile(MF_FL<14>{}, I1{}, I1{}, I2{}, I0{}, (b >> 1) + 1, 0);
   }
   // ---- last pair (b = n - 2): G1(n - 1) + second half of GELU(n - 2); G2(n - 2) + first half of GELU(n - 1);
   //      then the second half of GELU(n - 1) in the open (nothing left to hide it under) and G2(n - 1)
-  run_tile(I0{}, I1{}, I0{}, I0{}, I1{}, b >> 1, 0);
-  run_tile(I0{}, I1{}, I1{}, I1{}, I1{}, b >> 1, 0);
-  run_tile(I0{}, I1{}, I2{}, I0{}, I1{}, b >> 1, 1);
-  run_tile(I1{}, I0{}, I0{}, I1{}, I2{}, b >> 1, 1);
-  run_tile(I1{}, I0{}, I1{}, I0{}, I2{}, b >> 1, 1);
-  run_tile(I1{}, I0{}, I2{}, I1{}, I2{}, b >> 1, 1);
+  run_tile(MF_FL<3>{}, I0{}, I1{}, I0{}, I1{}, b >> 1, 0);
+  run_tile(MF_FL<4>{}, I0{}, I1{}, I1{}, I1{}, b >> 1, 0);
+  run_tile(MF_FL<5>{}, I0{}, I1{}, I2{}, I1{}, b >> 1, 1);
+  run_tile(MF_FL<6>{}, I1{}, I0{}, I0{}, I2{}, b >> 1, 1);
+  run_tile(MF_FL<7>{}, I1{}, I0{}, I1{}, I2{}, b >> 1, 1);
+  run_tile(MF_FL<8>{}, I1{}, I0{}, I2{}, I2{}, b >> 1, 1);
   act_piece(0, b >> 1, 12); act_piece(0, b >> 1, 13); act_piece(0, b >> 1, 14); act_piece(0, b >> 1, 15);
-  run_tile(I1{}, I1{}, I0{}, I0{}, IM{}, 0, 1);
-  run_tile(I1{}, I1{}, I1{}, I1{}, IM{}, 0, 1);
-  run_tile(I1{}, I1{}, I2{}, I0{}, IM{}, 0, QKV ? 2 : 1);
+  run_tile(MF_FL<9>{}, I1{}, I1{}, I0{}, IM{}, 0, 1);
+  run_tile(MF_FL<10>{}, I1{}, I1{}, I1{}, IM{}, 0, 1);
+  run_tile(MF_FL<11>{}, I1{}, I1{}, I2{}, IM{}, 0, QKV ? 2 : 1);
 
+  MSTAMP(4);
   if constexpr (!QKV) {
     mf_wait_vmcnt<0>();   // the re-reads issued past the end
     // ---- epilogue: + b2 -> bf16 -> wave-private LDS transpose -> whole-line stores
@@ -722,19 +811,12 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     for (int nt = 0; nt < NQ / 128; ++nt) {
 #pragma unroll
       for (int kt = 0; kt < MF_KT; ++kt) {
-        // the 8 output stores of the previous n-tile are younger than the DMA group being waited for while
-        // kt <= 4 (that group was issued 5 tiles ago): allow them to stay in flight
-        if constexpr (!PAIR) {
-          if (nt > 0 && kt != MF_KT - 1) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + 8>();
-          else mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
-          __builtin_amdgcn_s_barrier();
-        } else if (kt % 2 == 0) {
-          // queue at (nt, 0): [DMA it+3 .. it+5][8 stores]; at (nt, 2): [DMA it+3][8 stores][DMA it+4, it+5]; at (nt, 4) the
-          // stores are older than everything that may stay in flight
-          if (nt > 0 && kt <= 2) mf_wait_vmcnt<MF_GL * 3 + 8>();
-          else mf_wait_vmcnt<MF_GL * 3>();
-          __builtin_amdgcn_s_barrier();
-        }
+        // the DMA group being waited for (tile it + 1) was issued during tile it + 1 - AHEAD; the 8 output stores of the
+        // previous n-tile were issued in front of (nt, 0): they are YOUNGER than that group while kt <= AHEAD - 2 and may
+        // then stay in flight
+        if (nt > 0 && kt <= MF_AHEAD - 2) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + 8>();
+        else mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
+        __builtin_amdgcn_s_barrier();
         const int itq = T0 + nt * MF_KT + kt;
         const int dma_tile = itq + MF_AHEAD < total ? itq + MF_AHEAD : total - 1;
         const int dma_stage = stage + MF_AHEAD >= MF_NST ? stage + MF_AHEAD - MF_NST : stage + MF_AHEAD;
@@ -900,20 +982,15 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
   // stagger only when there is more than one round of workgroups to keep de-phased; 100 MHz ticks
   static const int stagger_env = getenv("GWW_MLP_STAGGER") ? atoi(getenv("GWW_MLP_STAGGER")) : 0;
   const int stagger = panels >= 512 ? stagger_env : 0;
-  // one barrier per two weight tiles (PAIR) measured no different from one per tile (1.154 vs 1.159 ms plain, 1.653 vs
-  // 1.653 ms with the appended q/k/v, tools/run/mlp_ab.py): the round-1 form stays the default
-  const bool pair = getenv("GWW_MLP_PAIR") && atoi(getenv("GWW_MLP_PAIR")) != 0;   // read per call: in-process A/B
-#define GWW_MF_LAUNCH(QQ, PP, ...)                                                                                         \
-  hipLaunchKernelGGL((k_mlp_fused<QQ, PP>), dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta, \
+#define GWW_MF_LAUNCH(QQ, ...)                                                                                          \
+  hipLaunchKernelGGL((k_mlp_fused<QQ>), dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta, \
                      x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger, __VA_ARGS__)
   if (qkv) {
     float* xnx = x_next_out ? x_next_out : x_out;
     GWW_REQUIRE((((uintptr_t)xnx) & 15) == 0 && (const void*)xnx != (const void*)x, "mlp_fused: bad x_next_out");
-    if (pair) GWW_MF_LAUNCH(true, true, q_u, q_cb, (unsigned short*)q_out, NQ, xnx);
-    else GWW_MF_LAUNCH(true, false, q_u, q_cb, (unsigned short*)q_out, NQ, xnx);
+    GWW_MF_LAUNCH(true, q_u, q_cb, (unsigned short*)q_out, NQ, xnx);
   } else {
-    if (pair) GWW_MF_LAUNCH(false, true, nullptr, nullptr, nullptr, 0, nullptr);
-    else GWW_MF_LAUNCH(false, false, nullptr, nullptr, nullptr, 0, nullptr);
+    GWW_MF_LAUNCH(false, nullptr, nullptr, nullptr, 0, nullptr);
   }
 #undef GWW_MF_LAUNCH
   GWW_LAUNCH_CHECK();

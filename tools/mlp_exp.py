@@ -33,8 +33,8 @@ def t(fn):
 print("plain %%.4f ms   +qkv %%.4f ms" %% (t(lambda: ops.mlp_fused(x, dl, wt0, u, cb, b2)), t(lambda: ops.mlp_fused(x, dl, wt1, u, cb, b2, qkv=(uq, cq)))))
 ''' % ROOT
 for m in masks:
-    tag = m.replace("=", "").replace(",", "_")
-    defs = [f"-DGWW_MF_{kv}" for kv in m.split(",")]
+    tag = m.replace("=", "").replace(",", "_").replace("+", "").replace("-", "")
+    defs = [kv[1:] if kv.startswith("+") else f"-DGWW_MF_{kv}" for kv in m.split(",")]   # "+-fflag" passes a compiler flag
     o = os.path.join(out, f"mlp_fused_{tag}.o")
     so = os.path.join(out, f"libgww_{tag}.so")
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast", "-mllvm",

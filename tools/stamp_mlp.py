@@ -6,9 +6,13 @@ sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "gw_whisper_amd", "csrc")
 so = os.path.join(ROOT, "gpurun_out", "libgww_stamp.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-srcs = [f for f in sorted(os.listdir(csrc)) if f.endswith(".hip")]
+# only mlp_fused.hip is rebuilt (with the stamps); the other objects are the prebuilt ones of the production library
+objs = [os.path.join(csrc, "build", f) for f in sorted(os.listdir(os.path.join(csrc, "build"))) if f.endswith(".o") and f != "mlp_fused.o"]
+obj = os.path.join(ROOT, "gpurun_out", "mlp_fused_stamp.o")
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast",
-                "-DGWW_STAMP", "-mllvm", "-pragma-unroll-threshold=4000000"] + os.environ.get("GWW_EXTRA_DEFS", "").split() + ["-shared", "-o", so] + [os.path.join(csrc, f) for f in srcs], check=True)
+                "-DGWW_STAMP=" + os.environ.get("GWW_STAMP_MODE", "1"), "-mllvm", "-pragma-unroll-threshold=4000000"]
+               + os.environ.get("GWW_EXTRA_DEFS", "").split() + ["-c", os.path.join(csrc, "mlp_fused.hip"), "-o", obj], check=True)
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + [obj], check=True)
 import torch
 from gw_whisper_amd import _lib
 _lib.LIB_PATH = so
@@ -26,7 +30,12 @@ w2 = (torch.randn(d, ffn, device=dev) / ffn ** 0.5).bfloat16(); b2 = torch.randn
 w1_f, u1, c1 = ops.ln_fold_weights(w1.float(), lw, lb, b1)
 wt = ops.mlp_pack(w1_f, w2)
 fn = lambda: ops.mlp_fused(x, dl, wt, u1, c1, b2)
-names = ["prologue", "ring wait + barrier", "stage bookkeeping", "epilogue"] + ["-"] * 4 + [f"parity {i // 6} {'fc1' if i % 6 < 3 else 'fc2'} tile {i % 3}" for i in range(12)]
+if os.environ.get("GWW_STAMP_QKV") == "1":   # the variant with the next layer's LN1 + q / k / v appended
+    wq, bq = torch.randn(1152, d, device=dev) / d ** 0.5, torch.randn(1152, device=dev)
+    wq_f, uq, cq = ops.ln_fold_weights(wq, lw, lb, bq)
+    wtq = ops.mlp_pack(w1_f, w2, wq_f)
+    fn = lambda: ops.mlp_fused(x, dl, wtq, u1, c1, b2, qkv=(uq, cq))
+names = ["prologue", "ring wait + barrier", "stage bookkeeping", "epilogue", "main loop (light mode)"] + ["-"] * 3 + [f"parity {i // 6} {'fc1' if i % 6 < 3 else 'fc2'} tile {i % 3}" for i in range(12)]
 fn(); torch.cuda.synchronize()
 buf = (C.c_ulonglong * 24)()
 lib.gww_debug_stamps_mlp(buf, 1)
@@ -39,6 +48,8 @@ torch.cuda.synchronize()
 lib.gww_debug_stamps_mlp(buf, 1)
 waves = buf[23]
 tot = sum(buf[i] for i in range(20))
-print(f"mlp_fused B={B}: {ev0.elapsed_time(ev1) / 3:.3f} ms/launch (stamped build); waves {waves}, mean s_memtime ticks/wave {tot / waves:.0f}")
-for i in [0, 1, 2, 3] + list(range(8, 20)):
-    print(f"   {names[i]:26s} {buf[i] / waves:10.0f} ticks/wave  {100.0 * buf[i] / tot:5.1f} %")
+print(f"[{os.environ.get('GWW_EXTRA_DEFS', '')}] mlp_fused B={B}: {ev0.elapsed_time(ev1) / 3:.3f} ms/launch (stamped build); waves {waves}, mean s_memtime ticks/wave {tot / waves:.0f}")
+print(f"   shader clock held under the kernel: {100.0 * buf[22] / max(buf[21], 1):.0f} MHz (s_memtime / s_memrealtime ticks over each wave's life)")
+for i in [0, 1, 2, 3, 4] + list(range(8, 20)):
+    if buf[i]:
+        print(f"   {names[i]:26s} {buf[i] / waves:10.0f} ticks/wave  {100.0 * buf[i] / tot:5.1f} %")
