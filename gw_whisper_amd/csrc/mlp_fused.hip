@@ -63,6 +63,9 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #ifndef GWW_MF_AF_AGPR
 #define GWW_MF_AF_AGPR 0   // how many of the 24 A-operand fragments (4 registers each) are pinned to the accumulator file
 #endif
+#ifndef GWW_MF_DMAGAP
+#define GWW_MF_DMAGAP 1
+#endif
 #ifndef GWW_MF_NORM
 #define GWW_MF_NORM 1   // 1: the A operand is normalised once per panel, a^ = bf16((a - mean') rstd), so the fc1 / q,k,v outputs need
                         // only + cb (0: round 1's per-value LayerNorm algebra rstd (acc - mean' u) + cb: two more VALU
@@ -117,13 +120,14 @@ __device__ unsigned long long g_stamp_mlp[24];
   const unsigned long long _tb = _t0, _rb = __builtin_amdgcn_s_memrealtime();
 #define MSTAMP(i)                                                  \
   do {                                                             \
-    if (GWW_STAMP == 2 && (i) != 0 && (i) != 3 && (i) != 4) break; \
+    if (GWW_STAMP >= 2 && (i) != 0 && (i) != 3 && (i) != 4 && (i) != 5 && !((i) >= 100)) break; \
     __builtin_amdgcn_sched_barrier(0);                             \
     const unsigned long long _t1 = __builtin_amdgcn_s_memtime();   \
-    _acc[i] += _t1 - _t0;                                          \
+    _acc[(i) >= 100 ? (i) - 100 : (i)] += _t1 - _t0;               \
     _t0 = _t1;                                                     \
     __builtin_amdgcn_sched_barrier(0);                             \
   } while (0)
+#define TSTAMP(i) do { if (GWW_STAMP == 3) MSTAMP(100 + (i)); } while (0)   /* q/k/v tail detail (mode 3) */
 #define MSTAMP_FLUSH                                                                 \
   if (lane == 0) {                                                                   \
     for (int _q = 0; _q < 20; ++_q) atomicAdd(&g_stamp_mlp[_q], _acc[_q]);           \
@@ -134,6 +138,7 @@ __device__ unsigned long long g_stamp_mlp[24];
 #else
 #define MSTAMP_DECL
 #define MSTAMP(i)
+#define TSTAMP(i)
 #define MSTAMP_FLUSH
 #endif
 }  // namespace
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 
   MSTAMP_DECL
   for (int i = tid; i < F; i += MF_THREADS) {
-    lds_cb[i] = ln_cb[i];
+    lds_cb[i] = GWW_MF_SCHED ? ln_cb[i] * 0.125f : ln_cb[i];   // SCHED: the fc1 accumulators hold S / 8 (gelu_slice)
     lds_u[i] = ln_u[i];
   }
   for (int i = tid; i < MF_D; i += MF_THREADS) lds_b2[i] = b2[i];
@@ -362,6 +367,10 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   float a_u[2][4], a_b[2][4], a_v[2][4];
   auto act_begin = [&](int slot, int c, int p) {
     if (GWW_MF_EXP & 2) return;
+    if (GWW_MF_SCHED) {   // the folded bias is the accumulators' initial value (preload_bias): nothing to add
+      a_b[slot][0] = a_b[slot][1] = a_b[slot][2] = a_b[slot][3] = 0.f;
+      return;
+    }
     const int nl = 128 * c + 32 * (p >> 2) + 8 * (p & 3) + 4 * hh;
 #if !GWW_MF_NORM
     const float4 uv = *reinterpret_cast<const float4*>(lds_u + nl);
@@ -379,7 +388,9 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       a_v[slot][e] = sacc[p >> 2][4 * (p & 3) + e];
       return;
     }
-#if GWW_MF_NORM
+#if GWW_MF_SCHED
+    a_v[slot][e] = 0.125f * gelu_sig(8.0f * sacc[p >> 2][4 * (p & 3) + e]);   // S / 8 in, gelu / 8 out (both exact)
+#elif GWW_MF_NORM
     a_v[slot][e] = gelu_sig(sacc[p >> 2][4 * (p & 3) + e] + a_b[slot][e]);
 #else
     a_v[slot][e] = gelu_sig(fmaf(row_rstd, fmaf(-row_mean, a_u[slot][e], sacc[p >> 2][4 * (p & 3) + e]), a_b[slot][e]));
@@ -420,39 +431,46 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   // 1 .. 11 (B).  The four bias values of group k + 1 are read from LDS in gap 6 of group k (group 0 of the NEXT phase in
   // gap 42: phases advance through the folded-bias vector by 32 floats, so its address is this phase's + 32).
   float g_t[4] = {0.f, 0.f, 0.f, 0.f}, g_w[4] = {0.f, 0.f, 0.f, 0.f}, g_q[4] = {0.f, 0.f, 0.f, 0.f};
-  float4 g_b[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#define MF_FENCE(FRAG)                                                                                                   \
-  asm volatile("" : "+v"(FRAG), "+v"(g_t[0]), "+v"(g_t[1]), "+v"(g_t[2]), "+v"(g_t[3]), "+v"(g_w[0]), "+v"(g_w[1]),     \
-               "+v"(g_w[2]), "+v"(g_w[3]), "+v"(g_q[0]), "+v"(g_q[1]), "+v"(g_q[2]), "+v"(g_q[3]))
-  auto gelu_bias_addr = [&](int t, int cpair, int k) -> const float4* {
-    return reinterpret_cast<const float4*>(lds_cb + 128 * cpair + 32 * t + 8 * k + 4 * hh);
+#define MF_FENCE()                                                                                                       \
+  asm volatile("" : "+v"(g_t[0]), "+v"(g_t[1]), "+v"(g_t[2]), "+v"(g_t[3]), "+v"(g_w[0]), "+v"(g_w[1]), "+v"(g_w[2]),   \
+               "+v"(g_w[3]), "+v"(g_q[0]), "+v"(g_q[1]), "+v"(g_q[2]), "+v"(g_q[3]))
+  // The folded fc1 bias cb is the INITIAL VALUE of the fc1 accumulators: the 16 values of S index t of 64-column chunk c
+  // (register e holds column 64 c + 32 (t & 1) + 8 (e >> 2) + 4 hh + (e & 3)) are read from LDS straight into the
+  // accumulator registers, one ds_read_b128 per gap, in the phase in which that accumulator pair is idle (its GELU has
+  // been consumed, the chunk's first MFMA is three tiles away).  The per-value bias add (one VALU instruction per
+  // activation value) and its LDS read in front of the GELU chain are gone.
+  auto preload_bias = [&](int t, int chunk, int q) {
+    const float4 bv = *reinterpret_cast<const float4*>(lds_cb + 64 * chunk + 32 * (t & 1) + 8 * q + 4 * hh);
+    sacc[t][4 * q] = bv.x; sacc[t][4 * q + 1] = bv.y; sacc[t][4 * q + 2] = bv.z; sacc[t][4 * q + 3] = bv.w;
   };
-  auto gelu_slice = [&](int t, int cpair, int g) {   // t, g are compile-time constants after unrolling
+  auto gelu_slice = [&](int t, int g) {   // t, g are compile-time constants after unrolling
     if (GWW_MF_EXP & 2) return;
     const int k = g / 12, j = g % 12;
-    if (j == 6) g_b[(k + 1) & 1] = *gelu_bias_addr(t, cpair, k + 1);   // k + 1 == 4: group 0 of the next phase
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
       const int op = j - pr;
-      if (op < 0 || op > 10) continue;
+      if (op < 0 || op > 8) continue;
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
         const int i = 2 * pr + sl, v = 4 * k + i;
+        const float S_ = sacc[t][v];
         float& T_ = g_t[i];
         float& W_ = g_w[i];
         float& Q_ = g_q[i];
-        const float4& bb = g_b[k & 1];
-        if (op == 0) T_ = sacc[t][v] + (i == 0 ? bb.x : (i == 1 ? bb.y : (i == 2 ? bb.z : bb.w)));
-        else if (op == 1) W_ = T_ * T_;
-        else if (op == 2) asm("v_min_f32 %0, 0x42800000, %0" : "+v"(W_));   // min(x^2, 64): plain fminf adds a canonicalising v_max behind the fence
-        else if (op == 3) Q_ = fmaf(W_, 0.0010148164f, -0.1067791331f);
-        else if (op == 4) Q_ = fmaf(W_, Q_, -2.3011178f);
-        else if (op == 5) W_ = T_ * Q_;
-        else if (op == 6) W_ = __builtin_amdgcn_exp2f(W_);
-        else if (op == 7) W_ = 1.0f + W_;
-        else if (op == 8) W_ = __builtin_amdgcn_rcpf(W_);
-        else if (op == 9) T_ = T_ * W_;
-        else if (op == 10 && sl == 1) pf[t][k >> 1][2 * (k & 1) + pr] = pack2bf(g_t[2 * pr], g_t[2 * pr + 1]);
+        // x = 8 S_:  s' = min(x^2, 64) / 64 = clamp(S_^2) is ONE instruction (the VOP3 clamp modifier),
+        // -log2(e) p(x) x = S_ (C1 + s' (C3 + s' C5)) with the powers of 8 folded into the constants
+        if (op == 0) asm("v_mul_f32_e64 %0, %1, %1 clamp" : "=v"(W_) : "v"(S_));
+        else if (op == 1) Q_ = fmaf(W_, 33.2535038f, -54.67091615f);
+        else if (op == 2) Q_ = fmaf(W_, Q_, -18.4089424f);
+        else if (op == 3) W_ = S_ * Q_;
+        else if (op == 4) W_ = __builtin_amdgcn_exp2f(W_);
+        else if (op == 5) W_ = 1.0f + W_;
+        else if (op == 6) W_ = __builtin_amdgcn_rcpf(W_);
+        else if (op == 7) T_ = S_ * W_;
+        else if (op == 8 && sl == 1) {
+          pf[t][k >> 1][2 * (k & 1) + pr] = pack2bf(g_t[2 * pr], g_t[2 * pr + 1]);
+          asm volatile("" : "+v"(pf[t][k >> 1][2 * (k & 1) + pr]));   // the pack stays in this gap
+        }
       }
     }
   };
@@ -490,9 +508,15 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   // KIND 1: fc2 tile ng with P = pf[2 PAR + ..].  ride_t >= 0: S index whose GELU values ride in this tile
   // (values v0 .. of its four pieces, 16 per S index, spread 1-1-2 over the 12 steps of a phase);
   // next_kind: kind of the tile that follows (its first fragments are prefetched in the last step).
-  auto run_tile = [&](auto flat_c, auto kind_c, auto par_c, auto idx3_c, auto ride_t_c, int ride_cpair, int next_kind) {
+  auto run_tile = [&](auto flat_c, auto kind_c, auto par_c, auto idx3_c, auto ride_t_c, int ride_cpair, int next_kind,
+                      auto pre_c, int pre_chunk, auto pad_c) {
     constexpr int KIND = decltype(kind_c)::value, PAR = decltype(par_c)::value, IDX3 = decltype(idx3_c)::value;
     constexpr int RIDE_T = decltype(ride_t_c)::value;
+    // PAD: the asm MFMAs of the tiles outside the main loop carry two wait states in front: there hipcc may place register
+    // copies (v_accvgpr_mov / _write into an accumulator tile it re-homes between the loop and the epilogue) directly in
+    // front of an MFMA it cannot recognise inside an asm statement; the build's ISA audit checks that none is left.
+    constexpr bool PAD = decltype(pad_c)::value != 0;
+    constexpr int PRE = decltype(pre_c)::value;   // >= 0: parity of the accumulator pair whose bias is preloaded in this tile
     // A four-stage ring makes the stage of every tile of the unrolled 12-tile body a compile-time constant (flat tile
     // index mod 4): every fragment address is then base register + immediate (no v_or_b32 per read: 8 cycles each
     // beside an MFMA, tools/ubench/mfma_gap.hip) and the DMA destination needs no wrap-around arithmetic.
@@ -516,7 +540,12 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       const int j12 = 4 * IDX3 + sub;
       const int v0 = (16 * j12) / 12, v1 = (16 * (j12 + 1)) / 12;
       __builtin_amdgcn_sched_barrier(0);
-      if (!(GWW_MF_EXP & 1)) issue_piece(dma_tile, dma_stage, sub);
+      // DMA pieces: in a riding tile they go into the gaps the GELU schedule leaves (nearly) empty -- gaps 9, 10, 11 of
+      // every 12-gap group carry at most the pack, gap 0 only pair A's first operation: phase gaps 9 .. 12, 21 .. 24,
+      // 33 .. 36, i.e. tile-local gaps 9 .. 12 / 5 .. 8 / 1 .. 4 of tiles 0 / 1 / 2 of the phase (an LDS-DMA piece costs
+      // ~27 cycles of issue when it shares a gap with a full slice, tools/ubench/mfma_gap.hip); elsewhere one per step
+      constexpr bool DMA_IN_GAPS = GWW_MF_SCHED && GWW_MF_DMAGAP && RIDE_T >= 0;
+      if (!(GWW_MF_EXP & 1) && !DMA_IN_GAPS) issue_piece(dma_tile, dma_stage, sub);
       if (!GWW_MF_SCHED && RIDE_T >= 0) {
 #pragma unroll
         for (int v = v0; v < v1; ++v) {
@@ -538,15 +567,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
             // and then copies all 16 values out with v_accvgpr_read_b32 for the GELU -- 8 cycles each beside an MFMA,
             // tools/ubench/mfma_gap.hip).  The GELU reads S two or more MFMAs after the last one that wrote it (the
             // slices are pinned into their gaps), which covers the MFMA-write -> VALU-read interval hipcc cannot see here.
-            f32x16& acc = sacc[2 * PAR + tl];
-            const bool first = IDX3 == 0 && ks == 0;
-            if (afi < MF_AF_AGPR) {
-              if (first) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(cur[u]), "a"(af[afi]));
-              else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(cur[u]), "a"(af[afi]));
-            } else {
-              if (first) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(cur[u]), "v"(af[afi]));
-              else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(cur[u]), "v"(af[afi]));
-            }
+            if (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[2 * PAR + tl]) : "v"(cur[u]), "v"(af[afi]));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[2 * PAR + tl]) : "v"(cur[u]), "v"(af[afi]));
           } else if (IDX3 == 0 && ks == 0) {
             f32x16 z;
 #pragma unroll
@@ -557,18 +579,22 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           }
         } else {
           // ---- fc2: O[4 ng + u] += W2 tile (rows 32 u ..) . P[k-step];  ng = IDX3
-          oacc[4 * IDX3 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              cur[u], __builtin_bit_cast(bf16x8, pf[2 * PAR + (sub >> 1)][sub & 1]), oacc[4 * IDX3 + u], 0, 0, 0);
+          if (GWW_MF_SCHED && PAD)
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
+                         : "+a"(oacc[4 * IDX3 + u]) : "v"(cur[u]), "v"(pf[2 * PAR + (sub >> 1)][sub & 1]));
+          else if (GWW_MF_SCHED)   // asm: volatile statements keep their order, so no fence has to name an MFMA operand (below)
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
+                         : "+a"(oacc[4 * IDX3 + u]) : "v"(cur[u]), "v"(pf[2 * PAR + (sub >> 1)][sub & 1]));
+          else
+            oacc[4 * IDX3 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                cur[u], __builtin_bit_cast(bf16x8, pf[2 * PAR + (sub >> 1)][sub & 1]), oacc[4 * IDX3 + u], 0, 0, 0);
         }
-        // hipcc moves MFMAs across sched_barrier(0) relative to the (independent) GELU chain; empty volatile asm statements
-        // that name BOTH a W fragment of the adjacent MFMA and the GELU state pin the order: MFMA u | fence (clobbers the
-        // fragment MFMA u has just read: write-after-read) | fragment read + four GELU instructions | fence (defines the
-        // fragment MFMA u + 1 reads) | MFMA u + 1.  (Naming the ACCUMULATOR instead makes hipcc wait out the MFMA's
-        // result latency in front of every fence: measured 0.2 ms slower per launch.)
+        // Every MFMA of the riding tiles is a volatile asm statement and so is the fence behind each slice: their order is
+        // the program's.  The fence names ONLY the GELU state: a fence that (re)defined the next MFMA's W fragment made
+        // hipcc pad every MFMA with an s_nop (it must assume a VALU write two wait states in front of an MFMA read; 3.5
+        // cycles per gap, tools/ubench/mfma_gap.hip).  The fragment's own "definition" below sits in front of the slice:
+        // the counted LDS wait for MFMA u + 1 lands there and the slice fills the wait states.
         if (GWW_MF_SCHED && RIDE_T >= 0) {
-          MF_FENCE(cur[u]);
-          // the wait for the NEXT MFMA's fragment lands here, in front of the slice: the VALU instructions of the slice
-          // then fill the wait state hipcc otherwise pads with an s_nop between an s_waitcnt and the MFMA
           if (u < 3) asm volatile("" : "+v"(cur[u + 1]));
           else if (sub < 3) asm volatile("" : "+v"(nxt[0]));
         }
@@ -579,9 +605,13 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + off);
         }
         if (GWW_MF_SCHED && RIDE_T >= 0) {
-          gelu_slice(RIDE_T, ride_cpair, 16 * IDX3 + 4 * sub + u);
-          if (u < 3) MF_FENCE(cur[u + 1]);   // tie the slice in front of the next MFMA of this step
-          else if (sub < 3) MF_FENCE(nxt[0]);  // ... of the next step (its fragments are this step's `nxt`)
+          if (PRE >= 0 && 4 * sub + u < 8) preload_bias(2 * PRE + ((4 * sub + u) >> 2), pre_chunk, (4 * sub + u) & 3);
+          gelu_slice(RIDE_T, 16 * IDX3 + 4 * sub + u);
+          if (DMA_IN_GAPS && !(GWW_MF_EXP & 1)) {
+            const int piece = 4 * sub + u - (9 - 4 * IDX3);
+            if (piece >= 0 && piece < 4) issue_piece(dma_tile, dma_stage, piece);
+          }
+          MF_FENCE();
         }
       }
       if (GWW_MF_SCHED) continue;
@@ -610,45 +640,57 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   using I3 = std::integral_constant<int, 3>;
   using IM = std::integral_constant<int, -1>;
 
+  if (GWW_MF_SCHED) {   // bias of chunks 0 and 1 into S[0..1] and S[2..3] (later chunks: in the tiles marked below)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) preload_bias(t, t >> 1, q);
+  }
   // G1(0): no GELU to carry yet; its first half is then computed in the open (once per 128 rows)
-  run_tile(MF_FL<0>{}, I0{}, I0{}, I0{}, IM{}, 0, 0);
-  run_tile(MF_FL<1>{}, I0{}, I0{}, I1{}, IM{}, 0, 0);
-  run_tile(MF_FL<2>{}, I0{}, I0{}, I2{}, IM{}, 0, 0);
+  run_tile(MF_FL<0>{}, I0{}, I0{}, I0{}, IM{}, 0, 0, IM{}, 0, I1{});
+  run_tile(MF_FL<1>{}, I0{}, I0{}, I1{}, IM{}, 0, 0, IM{}, 0, I1{});
+  run_tile(MF_FL<2>{}, I0{}, I0{}, I2{}, IM{}, 0, 0, IM{}, 0, I1{});
+  // (hipcc cannot see that the asm MFMAs write S: the MFMA-write -> VALU-read interval is padded by hand)
+  if (GWW_MF_SCHED) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(sacc[2]), "+v"(sacc[3]));
   act_piece(0, 0, 0); act_piece(0, 0, 1); act_piece(0, 0, 2); act_piece(0, 0, 3);
-  if (GWW_MF_SCHED) g_b[0] = *gelu_bias_addr(1, 0, 0);   // group 0 of the first riding phase (S index 1 of chunk pair 0)
   int b = 0;
   for (; b + 2 < nck; b += 2) {
     // ---- block b (parity 0): G1(b + 1) -> S[2..3] carrying the second half of GELU(b) (S[1]);
     //      G2(b) with pf[0..1] carrying the first half of GELU(b + 1) (S[2])
-    run_tile(MF_FL<3>{}, I0{}, I1{}, I0{}, I1{}, b >> 1, 0);
-    run_tile(MF_FL<4>{}, I0{}, I1{}, I1{}, I1{}, b >> 1, 0);
-    run_tile(MF_FL<5>{}, I0{}, I1{}, I2{}, I1{}, b >> 1, 1);
-    run_tile(MF_FL<6>{}, I1{}, I0{}, I0{}, I2{}, b >> 1, 1);
-    run_tile(MF_FL<7>{}, I1{}, I0{}, I1{}, I2{}, b >> 1, 1);
-    run_tile(MF_FL<8>{}, I1{}, I0{}, I2{}, I2{}, b >> 1, 0);
+    run_tile(MF_FL<3>{}, I0{}, I1{}, I0{}, I1{}, b >> 1, 0, IM{}, 0, I0{});
+    run_tile(MF_FL<4>{}, I0{}, I1{}, I1{}, I1{}, b >> 1, 0, IM{}, 0, I0{});
+    run_tile(MF_FL<5>{}, I0{}, I1{}, I2{}, I1{}, b >> 1, 1, IM{}, 0, I0{});
+    run_tile(MF_FL<6>{}, I1{}, I0{}, I0{}, I2{}, b >> 1, 1, I0{}, b + 2, I0{});
+    run_tile(MF_FL<7>{}, I1{}, I0{}, I1{}, I2{}, b >> 1, 1, IM{}, 0, I0{});
+    run_tile(MF_FL<8>{}, I1{}, I0{}, I2{}, I2{}, b >> 1, 0, IM{}, 0, I0{});
     // ---- block b + 1 (parity 1): G1(b + 2) -> S[0..1] carrying the second half of GELU(b + 1) (S[3]);
     //      G2(b + 1) with pf[2..3] carrying the first half of GELU(b + 2) (S[0])
-    run_tile(MF_FL<9>{}, I0{}, I0{}, I0{}, I3{}, b >> 1, 0);
-    run_tile(MF_FL<10>{}, I0{}, I0{}, I1{}, I3{}, b >> 1, 0);
-    run_tile(MF_FL<11>{}, I0{}, I0{}, I2{}, I3{}, b >> 1, 1);
-    run_tile(MF_FL<12>{}, I1{}, I1{}, I0{}, I0{}, (b >> 1) + 1, 1);
-    run_tile(MF_FL<13>{}, I1{}, I1{}, I1{}, I0{}, (b >> 1) + 1, 1);
-    run_tile(MF_FL<14>{}, I1{}, I1{}, I2{}, I0{}, (b >> 1) + 1, 0);
+    run_tile(MF_FL<9>{}, I0{}, I0{}, I0{}, I3{}, b >> 1, 0, IM{}, 0, I0{});
+    run_tile(MF_FL<10>{}, I0{}, I0{}, I1{}, I3{}, b >> 1, 0, IM{}, 0, I0{});
+    run_tile(MF_FL<11>{}, I0{}, I0{}, I2{}, I3{}, b >> 1, 1, IM{}, 0, I0{});
+    run_tile(MF_FL<12>{}, I1{}, I1{}, I0{}, I0{}, (b >> 1) + 1, 1, I1{}, b + 3, I0{});
+    run_tile(MF_FL<13>{}, I1{}, I1{}, I1{}, I0{}, (b >> 1) + 1, 1, IM{}, 0, I0{});
+    run_tile(MF_FL<14>{}, I1{}, I1{}, I2{}, I0{}, (b >> 1) + 1, 0, IM{}, 0, I0{});
   }
   // ---- last pair (b = n - 2): G1(n - 1) + second half of GELU(n - 2); G2(n - 2) + first half of GELU(n - 1);
   //      then the second half of GELU(n - 1) in the open (nothing left to hide it under) and G2(n - 1)
-  run_tile(MF_FL<3>{}, I0{}, I1{}, I0{}, I1{}, b >> 1, 0);
-  run_tile(MF_FL<4>{}, I0{}, I1{}, I1{}, I1{}, b >> 1, 0);
-  run_tile(MF_FL<5>{}, I0{}, I1{}, I2{}, I1{}, b >> 1, 1);
-  run_tile(MF_FL<6>{}, I1{}, I0{}, I0{}, I2{}, b >> 1, 1);
-  run_tile(MF_FL<7>{}, I1{}, I0{}, I1{}, I2{}, b >> 1, 1);
-  run_tile(MF_FL<8>{}, I1{}, I0{}, I2{}, I2{}, b >> 1, 1);
+  run_tile(MF_FL<3>{}, I0{}, I1{}, I0{}, I1{}, b >> 1, 0, IM{}, 0, I1{});
+  run_tile(MF_FL<4>{}, I0{}, I1{}, I1{}, I1{}, b >> 1, 0, IM{}, 0, I1{});
+  run_tile(MF_FL<5>{}, I0{}, I1{}, I2{}, I1{}, b >> 1, 1, IM{}, 0, I1{});
+  run_tile(MF_FL<6>{}, I1{}, I0{}, I0{}, I2{}, b >> 1, 1, IM{}, 0, I1{});
+  run_tile(MF_FL<7>{}, I1{}, I0{}, I1{}, I2{}, b >> 1, 1, IM{}, 0, I1{});
+  run_tile(MF_FL<8>{}, I1{}, I0{}, I2{}, I2{}, b >> 1, 1, IM{}, 0, I1{});
+  if (GWW_MF_SCHED) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(sacc[2]), "+v"(sacc[3]));
   act_piece(0, b >> 1, 12); act_piece(0, b >> 1, 13); act_piece(0, b >> 1, 14); act_piece(0, b >> 1, 15);
-  run_tile(MF_FL<9>{}, I1{}, I1{}, I0{}, IM{}, 0, 1);
-  run_tile(MF_FL<10>{}, I1{}, I1{}, I1{}, IM{}, 0, 1);
-  run_tile(MF_FL<11>{}, I1{}, I1{}, I2{}, IM{}, 0, QKV ? 2 : 1);
+  run_tile(MF_FL<9>{}, I1{}, I1{}, I0{}, IM{}, 0, 1, IM{}, 0, I1{});
+  run_tile(MF_FL<10>{}, I1{}, I1{}, I1{}, IM{}, 0, 1, IM{}, 0, I1{});
+  run_tile(MF_FL<11>{}, I1{}, I1{}, I2{}, IM{}, 0, QKV ? 2 : 1, IM{}, 0, I1{});
 
   MSTAMP(4);
+  if (GWW_MF_SCHED)   // asm MFMAs -> accumulator reads of the epilogue (as above); the operands keep the reads behind the pad
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]), "+a"(oacc[3]), "+a"(oacc[4]), "+a"(oacc[5]), "+a"(oacc[6]),
+                   "+a"(oacc[7]), "+a"(oacc[8]), "+a"(oacc[9]), "+a"(oacc[10]), "+a"(oacc[11]));
   if constexpr (!QKV) {
     mf_wait_vmcnt<0>();   // the re-reads issued past the end
     // ---- epilogue: + b2 -> bf16 -> wave-private LDS transpose -> whole-line stores
@@ -805,6 +847,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     mf_wait_vmcnt<0>();               // x_next stores retired, every tile issued so far has landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();     // ... and everybody else's; u / cb visible
 
+    MSTAMP(5);
     // ---- second GEMM: qkv[32 rows, NQ] = LN1(x_next) Wqkv'^T, n-tiles of 128 columns, 6 k-tiles each
     const int T0 = 6 * nck;
     f32x16 acc[4];
@@ -817,6 +860,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         if (nt > 0 && kt <= MF_AHEAD - 2) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + 8>();
         else mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
         __builtin_amdgcn_s_barrier();
+        TSTAMP(6);
         const int itq = T0 + nt * MF_KT + kt;
         const int dma_tile = itq + MF_AHEAD < total ? itq + MF_AHEAD : total - 1;
         const int dma_stage = stage + MF_AHEAD >= MF_NST ? stage + MF_AHEAD - MF_NST : stage + MF_AHEAD;
@@ -856,6 +900,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           __builtin_amdgcn_sched_barrier(0);
         }
         stage = stage_next;
+        TSTAMP(7);
       }
       // n-tile epilogue: LayerNorm algebra + bias -> bf16 -> slice transpose -> whole-line stores (8 per wave)
 #pragma unroll
@@ -889,10 +934,23 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         }
       }
     }
-    mf_wait_vmcnt<0>();   // the re-reads issued past the end
+    // the ring's re-reads issued past the end must have landed before this workgroup's LDS is handed on; they are older
+    // than the last n-tile's 8 output stores, which need not be waited for (vmcnt counts in issue order)
+    mf_wait_vmcnt<8>();
   }
   MSTAMP(3);
   MSTAMP_FLUSH
+}
+
+// bf16 x 2^k is exact (no mantissa change) short of the exponent range's ends: the rescaled panels carry the same
+// information and every product of the rescaled GEMMs equals the unscaled one times an exact power of two.
+__device__ __forceinline__ u32x4 mf_scale_bf16x8(u32x4 v, float f) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float lo = __uint_as_float(v[j] << 16) * f, hi = __uint_as_float(v[j] & 0xffff0000u) * f;
+    v[j] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+  }
+  return v;
 }
 
 // Pre-tile the two weight panels of the block into the stream k_mlp_fused consumes:
@@ -931,6 +989,7 @@ __global__ __launch_bounds__(256) void k_mlp_pack(const unsigned short* __restri
         // fc1 tile [64 n][128 k]: 16 chunks per row, chunk ch stored at ch ^ (row & 15); k-third idx3
         const int row2 = within >> 4, ch = (within & 15) ^ (row2 & 15);
         v = *reinterpret_cast<const u32x4*>(w1 + (long)(64 * cp + row2) * MF_D + 128 * idx3 + 8 * ch);
+        if (GWW_MF_SCHED) v = mf_scale_bf16x8(v, 0.125f);   // S / 8 in the accumulators (header of gelu_slice)
       } else {
         // fc2 tile [128 n2][64 k]: n-group idx3, k = the 64 ffn columns of chunk cp, bits 2 / 3 of k swapped
         const unsigned short* src = w2 + (long)(128 * idx3 + row) * F + 64 * cp;
@@ -942,6 +1001,7 @@ __global__ __launch_bounds__(256) void k_mlp_pack(const unsigned short* __restri
         }
         v = u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
                   (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+        if (GWW_MF_SCHED) v = mf_scale_bf16x8(v, 8.0f);     // ... and gelu / 8 in the fc2 operand: fc2 x 8 restores it
       }
     }
     reinterpret_cast<u32x4*>(out)[g] = v;

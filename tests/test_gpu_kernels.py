@@ -416,7 +416,9 @@ def test_dora_merge(T, gww, d_out, d_in, r):
 def test_mlp_pack_layout(T, gww):
     """Tile stream of the fused MLP, in the order the kernel consumes it over 64-column ffn chunks c':
     G1(0) | G1(1) G2(0) | G1(2) G2(1) | ... | G1(n-1) G2(n-2) | G2(n-1); fc1 tiles are swizzled [64 n][128 k] images,
-    fc2 tiles [128 n][64 k] carry k with bits 2 / 3 swapped inside every 16-group."""
+    fc2 tiles [128 n][64 k] carry k with bits 2 / 3 swapped inside every 16-group.  The fc1 images hold W1' / 8 and the
+    fc2 images 8 W2 (exact powers of two: the kernel's fc1 accumulators then hold S / 8, which lets the GELU clamp ride
+    on an instruction modifier -- mlp_fused.hip, gelu_slice)."""
     from gw_whisper_amd import ops
     F, d = 256, 384
     w1 = T.arange(F * d, dtype=T.float32).reshape(F, d).remainder(251).cuda().bfloat16()
@@ -437,24 +439,16 @@ def test_mlp_pack_layout(T, gww):
             img = out[tile].reshape(64, 16, 8)
             for row in (0, 1, 17, 63):
                 logical = np.stack([img[row, ch ^ (row & 15)] for ch in range(16)]).reshape(128)
-                np.testing.assert_array_equal(logical, w1n[64 * cp + row, 128 * idx3:128 * idx3 + 128])
+                np.testing.assert_array_equal(logical, w1n[64 * cp + row, 128 * idx3:128 * idx3 + 128] / 8)
         else:                # fc2: [128 n2][64 k], chunk ^ ((row >> 1) & 7); n-group idx3, k = ffn columns of chunk cp
             img = out[tile].reshape(128, 8, 8)
             for row in (0, 1, 2, 77, 127):
                 logical = np.stack([img[row, ch ^ ((row >> 1) & 7)] for ch in range(8)]).reshape(64)
-                np.testing.assert_array_equal(logical, w2n[128 * idx3 + row, 64 * cp:64 * cp + 64][sw])
-
-
-@pytest.fixture(params=["single", "pair"])
-def mlp_ring(request, monkeypatch):
-    """Both ring disciplines of k_mlp_fused: one s_barrier per weight tile (default) and per two tiles (GWW_MLP_PAIR=1)."""
-    if request.param == "pair":
-        monkeypatch.setenv("GWW_MLP_PAIR", "1")
-    return request.param
+                np.testing.assert_array_equal(logical, 8 * w2n[128 * idx3 + row, 64 * cp:64 * cp + 64][sw])
 
 
 @pytest.mark.parametrize("M,F", [(128, 128), (1500, 1536), (777, 512), (4000, 1536), (70000, 1536)])
-def test_mlp_fused(T, gww, mlp_ring, M, F):
+def test_mlp_fused(T, gww, M, F):
     """LayerNorm -> fc1 -> GELU -> fc2 of (x + delta) in one kernel (mlp_fused.hip) against fp64:
     HF:modeling_whisper.py:401-407 without the residual add (deferred to the consumer)."""
     from gw_whisper_amd import ops
@@ -484,7 +478,7 @@ def test_mlp_fused(T, gww, mlp_ring, M, F):
 
 
 @pytest.mark.parametrize("M", [128, 1500, 4000])
-def test_mlp_fused_with_next_layers_qkv(T, gww, mlp_ring, M):
+def test_mlp_fused_with_next_layers_qkv(T, gww, M):
     """mlp_fused with the NEXT layer's LayerNorm1 + q / k / v projection appended: x_next = x + delta + bf16(mlp),
     qkv = Linear_qkv(LayerNorm1(x_next)) -- against fp64 (HF:modeling_whisper.py:392-407 across the layer seam)."""
     from gw_whisper_amd import ops

@@ -88,6 +88,103 @@ __global__ __launch_bounds__(256, 1) void k_gap(unsigned long long* out, int ite
   if (threadIdx.x == 0) out[0] = t1 - t0;
 }
 
+
+// The fused MLP's riding phase, gap by gap (48 gaps = 4 groups of 12; pair A of a group runs operation j in gap j, pair B
+// operation j - 1): MFMA | counted wait | fragment read | the slice | (every 4th gap) one LDS-DMA piece.
+// VARIANT bits: 1 no DMA, 2 transcendentals replaced by v_mul, 4 no s_nop in front of the MFMA, 8 no fragment read / wait,
+// 16 literal-constant fma replaced by register fma, 32 accumulators alternate between two registers only (fc1 shape)
+template <int VARIANT>
+__global__ __launch_bounds__(256, 1) void k_gelu(unsigned long long* out, int iters, float seed, const float* gbuf) {
+  __shared__ __attribute__((aligned(16))) float lds[8192 + 4096];
+  for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = seed * i;
+  __syncthreads();
+  f32x16 acc[4];
+  for (int t = 0; t < 4; ++t)
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(seed + j); b[j] = (__bf16)(seed - j); }
+  f32x4 frag8[8];
+  for (int j = 0; j < 8; ++j) frag8[j] = f32x4{seed, seed, seed, seed};
+  float S[4], W[4], Q[4], T[4];
+  for (int j = 0; j < 4; ++j) { S[j] = seed * (threadIdx.x + j); W[j] = Q[j] = T[j] = 0.f; }
+  float c = seed * 0.5f;
+  unsigned pk = 0;
+  f32x4 frag[4];
+  for (int j = 0; j < 4; ++j) frag[j] = f32x4{seed, seed, seed, seed};
+  const unsigned laddr = (threadIdx.x & 63) * 16;
+  const unsigned lane_off = (threadIdx.x & 63) * 16u;
+  const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned dma_dst = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds + 32768u + wave_u * 4096u;
+  const float* dma_src = gbuf + wave_u * 1024;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int g = 0; g < 48; ++g) {
+      const int u = g & 3;
+      if (!(VARIANT & 4)) asm volatile("s_nop 0");
+      if (VARIANT & 32) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[u & 1]) : "v"(a), "v"(b));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[u]) : "v"(a), "v"(b));
+      if (!(VARIANT & 8)) {
+        if (VARIANT & 64) asm volatile("s_waitcnt lgkmcnt(5)");      // fragment reads six gaps ahead of their use (8 buffers)
+        else if (VARIANT & 128) asm volatile("s_waitcnt lgkmcnt(3)"); // four gaps ahead
+        else asm volatile("s_waitcnt lgkmcnt(2)");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(frag8[g & 7]) : "v"(laddr), "n"(2048));
+      }
+      const int j = g % 12;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int op = j - pr;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          const int i = 2 * pr + sl;
+          if (op == 0) asm volatile("v_mul_f32_e64 %0, %1, %1 clamp" : "=v"(W[i]) : "v"(S[i]));
+          if (op == 1) {
+            if (VARIANT & 16) asm volatile("v_fma_f32 %0, %1, %2, %2" : "=v"(Q[i]) : "v"(W[i]), "v"(c));
+            else asm volatile("v_fmamk_f32 %0, %1, 0x42050396, %2" : "=v"(Q[i]) : "v"(W[i]), "v"(c));
+          }
+          if (op == 2) {
+            if (VARIANT & 16) asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(Q[i]) : "v"(W[i]), "v"(c));
+            else asm volatile("v_fmaak_f32 %0, %1, %0, 0xc1934584" : "+v"(Q[i]) : "v"(W[i]));
+          }
+          if (op == 3) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(W[i]) : "v"(S[i]), "v"(Q[i]));
+          if (op == 4) {
+            if (VARIANT & 2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(W[i]) : "v"(c));
+            else asm volatile("v_exp_f32 %0, %0" : "+v"(W[i]));
+          }
+          if (op == 5) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(W[i]));
+          if (op == 6) {
+            if (VARIANT & 2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(W[i]) : "v"(c));
+            else asm volatile("v_rcp_f32 %0, %0" : "+v"(W[i]));
+          }
+          if (op == 7) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(T[i]) : "v"(S[i]), "v"(W[i]));
+          if (op == 8 && sl == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(T[2 * pr]), "v"(T[2 * pr + 1]));
+        }
+      }
+      if (!(VARIANT & 1) && u == 0)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" :: "v"(lane_off), "s"(dma_src), "s"(dma_dst), "n"(1024) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int t = 0; t < 4; ++t)
+    for (int j = 0; j < 16; ++j) s += acc[t][j];
+  for (int j = 0; j < 4; ++j) s += T[j] + W[j] + Q[j] + frag[j][0] + frag[j][3];
+  for (int j = 0; j < 8; ++j) s += frag8[j][0] + frag8[j][3];
+  if (s == 12345.678f) out[2] = pk;
+  if (threadIdx.x == 0) out[0] = t1 - t0;
+}
+
+template <int VARIANT>
+static void run_gelu(const char* name, unsigned long long* d) {
+  const int iters = 700;
+  hipLaunchKernelGGL((k_gelu<VARIANT>), dim3(1), dim3(256), 0, 0, d, iters, 1e-3f, (const float*)(d + 8));
+  hipLaunchKernelGGL((k_gelu<VARIANT>), dim3(1), dim3(256), 0, 0, d, iters, 1e-3f, (const float*)(d + 8));
+  unsigned long long h = 0;
+  hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+  printf("riding phase, %-52s: %6.1f cycles per MFMA\n", name, (double)h / (48.0 * iters));
+}
+
 template <int KIND, int K, bool ACC_V>
 static void run(const char* name, unsigned long long* d) {
   const int iters = 2000;
@@ -122,6 +219,19 @@ int main() {
   SWEEP(F_VOR, "v_or_b32 v, s, v", false)
   SWEEP(F_GAP, "wait + read + (K-2) VALU", false)
   SWEEP(F_GAP_DMA, "same + DMA piece per 4 gaps", false)
+  run_gelu<0>("as in the kernel", d);
+  run_gelu<1>("no DMA", d);
+  run_gelu<2>("transcendentals -> v_mul", d);
+  run_gelu<3>("no DMA, transcendentals -> v_mul", d);
+  run_gelu<4>("no s_nop", d);
+  run_gelu<16>("literal fma -> register fma", d);
+  run_gelu<32>("two alternating VGPR accumulators (fc1 shape)", d);
+  run_gelu<128>("fragment wait lgkmcnt(3)", d);
+  run_gelu<64>("fragment wait lgkmcnt(5)", d);
+  run_gelu<64 | 4>("fragment wait lgkmcnt(5), no s_nop", d);
+  run_gelu<8>("no fragment read / wait", d);
+  run_gelu<9>("no fragment read / wait, no DMA", d);
+  run_gelu<1 | 2 | 4 | 16>("no DMA, no trans, no nop, no literals", d);
   hipFree(d);
   return 0;
 }
