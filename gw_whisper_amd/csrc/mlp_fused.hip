@@ -229,6 +229,13 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
   }
 
+  // The ring is filled FIRST: its AHEAD tiles land while the prologue runs (they used to be requested only after the
+  // prologue's last store had retired, and their L2 latency was exposed in front of the first tile).  Loads, stores
+  // and LDS-DMA retire in issue order, so the prologue's counted waits are unaffected by these OLDER operations, and
+  // the first ring wait (everything but the youngest AHEAD - 1 tiles... of a queue whose youngest entries are then the
+  // prologue's stores) at worst waits for more than it needs.
+#pragma unroll
+  for (int p = 0; p < MF_AHEAD; ++p) issue(p, p);
   // ---- prologue: x_new = x + delta (written back), a = bf16(x_new - c), exact fp32 row statistics
   bf16x8 af[MF_KT * 4];
   float row_rstd, row_mean;
@@ -303,6 +310,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         }
       }
     }
+    TSTAMP(8);
     float* stat = reinterpret_cast<float*>(slice);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -320,6 +328,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     row_rstd = stat[r];
     row_mean = stat[32 + r];
     asm volatile("" : "+v"(row_rstd), "+v"(row_mean)::"memory");
+    TSTAMP(9);
   }
 #if GWW_MF_NORM
   // normalise the panel in place (every lane owns the fragments of ITS row r): 96 registers x 5 instructions, once per panel
@@ -336,10 +345,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   };
   normalise_af();
 #endif
-  mf_wait_vmcnt<0>();   // every ordinary load / store is retired before the ring starts counting
   MSTAMP(0);
-#pragma unroll
-  for (int p = 0; p < MF_AHEAD; ++p) issue(p, p);
 
   // per-lane LDS offsets of the W fragments inside a tile
   //   fc1 tile [64 n][128 k], 256-byte rows, 16-byte chunk c stored at c ^ (row & 15):
@@ -476,8 +482,10 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   };
 
   // tile 0 landed (younger tiles may still be in flight)
-  mf_wait_vmcnt<MF_GL*(MF_AHEAD - 1)>();
+  TSTAMP(10);
+  mf_wait_vmcnt<0>();   // tiles 0 .. AHEAD - 1 (requested at the kernel's start) and the prologue's stores
   __builtin_amdgcn_s_barrier();
+  TSTAMP(11);
 
   // Software-pipelined schedule over 64-column ffn chunks c' = 0 .. n-1 (n = ffn / 64, even):
   //   G1(c') : three fc1 tiles [64 n][128 k] -> S[c' & 1]  (two 32-column accumulators)
@@ -651,8 +659,10 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   run_tile(MF_FL<1>{}, I0{}, I0{}, I1{}, IM{}, 0, 0, IM{}, 0, I1{});
   run_tile(MF_FL<2>{}, I0{}, I0{}, I2{}, IM{}, 0, 0, IM{}, 0, I1{});
   // (hipcc cannot see that the asm MFMAs write S: the MFMA-write -> VALU-read interval is padded by hand)
+  TSTAMP(12);
   if (GWW_MF_SCHED) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(sacc[2]), "+v"(sacc[3]));
   act_piece(0, 0, 0); act_piece(0, 0, 1); act_piece(0, 0, 2); act_piece(0, 0, 3);
+  TSTAMP(13);
   int b = 0;
   for (; b + 2 < nck; b += 2) {
     // ---- block b (parity 0): G1(b + 1) -> S[2..3] carrying the second half of GELU(b) (S[1]);

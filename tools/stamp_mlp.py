@@ -35,7 +35,7 @@ if os.environ.get("GWW_STAMP_QKV") == "1":   # the variant with the next layer's
     wq_f, uq, cq = ops.ln_fold_weights(wq, lw, lb, bq)
     wtq = ops.mlp_pack(w1_f, w2, wq_f)
     fn = lambda: ops.mlp_fused(x, dl, wtq, u1, c1, b2, qkv=(uq, cq))
-names = ["prologue", "ring wait + barrier", "stage bookkeeping", "epilogue", "main loop (light mode)", "x_next + LN1 (q/k/v variant)", "q/k/v tail: ring wait + barrier", "q/k/v tail: tile MFMAs"] + [f"parity {i // 6} {'fc1' if i % 6 < 3 else 'fc2'} tile {i % 3}" for i in range(12)]
+names = ["prologue", "ring wait + barrier", "stage bookkeeping", "epilogue", "main loop (light mode)", "x_next + LN1 (q/k/v variant)", "q/k/v tail: ring wait + barrier", "q/k/v tail: tile MFMAs"] + ([f"parity {i // 6} {'fc1' if i % 6 < 3 else 'fc2'} tile {i % 3}" for i in range(12)] if os.environ.get("GWW_STAMP_MODE", "1") != "3" else ["prologue: loads + x_new + pack (since kernel start)", "prologue: row statistics", "prologue: normalise + offsets", "prologue: ring wait + barrier", "G1(0): three tiles", "open GELU of chunk 0", "-", "-", "-", "-", "-", "-"])
 fn(); torch.cuda.synchronize()
 buf = (C.c_ulonglong * 24)()
 lib.gww_debug_stamps_mlp(buf, 1)
@@ -52,4 +52,4 @@ print(f"[{os.environ.get('GWW_EXTRA_DEFS', '')}] mlp_fused B={B}: {ev0.elapsed_t
 print(f"   shader clock held under the kernel: {100.0 * buf[22] / max(buf[21], 1):.0f} MHz (s_memtime / s_memrealtime ticks over each wave's life)")
 for i in [0, 1, 2, 3, 4, 5, 6, 7] + list(range(8, 20)):
     if buf[i]:
-        print(f"   {names[i]:26s} {buf[i] / waves:10.0f} ticks/wave  {100.0 * buf[i] / tot:5.1f} %")
+        print(f"   {names[i]:52s} {buf[i] / waves:10.0f} ticks/wave  {100.0 * buf[i] / tot:5.1f} %")
