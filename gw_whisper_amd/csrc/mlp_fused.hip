@@ -862,6 +862,15 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     const int T0 = 6 * nck;
     f32x16 acc[4];
     for (int nt = 0; nt < NQ / 128; ++nt) {
+#if GWW_MF_SCHED
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float4 bv = *reinterpret_cast<const float4*>(lds_cb + 128 * nt + 32 * t + 8 * cc + 4 * hh);
+          acc[t][4 * cc] = bv.x; acc[t][4 * cc + 1] = bv.y; acc[t][4 * cc + 2] = bv.z; acc[t][4 * cc + 3] = bv.w;
+        }
+#endif
 #pragma unroll
       for (int kt = 0; kt < MF_KT; ++kt) {
         // the DMA group being waited for (tile it + 1) was issued during tile it + 1 - AHEAD; the 8 output stores of the
@@ -885,6 +894,12 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           issue_piece(dma_tile, dma_stage, sub);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
+#if GWW_MF_SCHED
+            // accumulators in architectural registers, preloaded with the folded bias (below): the n-tile epilogue is a
+            // pack + store, no v_accvgpr_read_b32 (8 cycles each in the open), no bias read / add per value.  asm: see
+            // the main loop; two wait states in front cover register copies hipcc may place there (ISA audit in build())
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(cur[u]), "v"(af[4 * kt + sub]));
+#else
             if (kt == 0 && sub == 0) {
               f32x16 z;
 #pragma unroll
@@ -893,8 +908,10 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
             } else {
               acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[u], af[4 * kt + sub], acc[u], 0, 0, 0);
             }
+#endif
             nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + u * 4096);
           }
+#if !GWW_MF_SCHED   // (asm MFMAs and the fragment reads keep their program order without hints)
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
@@ -907,12 +924,16 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
         stage = stage_next;
         TSTAMP(7);
       }
       // n-tile epilogue: LayerNorm algebra + bias -> bf16 -> slice transpose -> whole-line stores (8 per wave)
+#if GWW_MF_SCHED
+      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));   // asm MFMA -> VALU read
+#endif
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -921,11 +942,15 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #pragma unroll
           for (int cc = 0; cc < 4; ++cc) {
             const int nl = 128 * nt + 32 * t + 8 * cc + 4 * hh;
+#if GWW_MF_SCHED
+            const float v0 = acc[t][4 * cc], v1 = acc[t][4 * cc + 1], v2 = acc[t][4 * cc + 2], v3 = acc[t][4 * cc + 3];
+            (void)nl;
+#elif GWW_MF_NORM
             const float4 bv = *reinterpret_cast<const float4*>(lds_cb + nl);
-#if GWW_MF_NORM
             const float v0 = acc[t][4 * cc] + bv.x, v1 = acc[t][4 * cc + 1] + bv.y;
             const float v2 = acc[t][4 * cc + 2] + bv.z, v3 = acc[t][4 * cc + 3] + bv.w;
 #else
+            const float4 bv = *reinterpret_cast<const float4*>(lds_cb + nl);
             const float4 uv = *reinterpret_cast<const float4*>(lds_u + nl);
             const float v0 = fmaf(row_rstd, fmaf(-row_mean, uv.x, acc[t][4 * cc]), bv.x);
             const float v1 = fmaf(row_rstd, fmaf(-row_mean, uv.y, acc[t][4 * cc + 1]), bv.y);
