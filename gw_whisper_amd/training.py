@@ -32,9 +32,7 @@ def dora_targets(encoder):
         for name, pid in _PROJ.items():
             mod = getattr(layer.self_attn, name)
             if isinstance(mod, DoraLinear):
-                if not mod.use_dora:
-                    raise NotImplementedError("training is implemented for use_dora=True adapters")
-                out.append((li, pid, mod))
+                out.append((li, pid, mod))   # use_dora=False (plain LoRA, the reference's --method LoRA) included
     return out
 
 
@@ -82,15 +80,23 @@ class _EncoderTrain(torch.autograd.Function):
             z = torch.zeros_like(like)
             return z, z
         for i, (li, pid, mod) in enumerate(targets):
-            pA, pB, pm = (mod.lora_A[mod.adapter].weight, mod.lora_B[mod.adapter].weight,
-                          mod.lora_magnitude_vector[mod.adapter].weight)
+            pA, pB = mod.lora_A[mod.adapter].weight, mod.lora_B[mod.adapter].weight
             A = pA.detach().float().contiguous()
             Bm = pB.detach().float().contiguous()
-            mag = pm.detach().float().contiguous()
-            nrm = mod._last_norm
-            (dA, rA), (dB, rB), (dm, rm) = grad_buffer(pA, A), grad_buffer(pB, Bm), grad_buffer(pm, mag)
-            keep += [A, Bm, mag, dA, dB, dm]
-            grads.append((rA, rB, rm))
+            (dA, rA), (dB, rB) = grad_buffer(pA, A), grad_buffer(pB, Bm)
+            if mod.use_dora:
+                pm = mod.lora_magnitude_vector[mod.adapter].weight
+                mag = pm.detach().float().contiguous()
+                nrm = mod._last_norm
+                dm, rm = grad_buffer(pm, mag)
+                grads.append((rA, rB, rm))
+            else:
+                # plain LoRA (peft tuners/lora/layer.py, use_dora=False: W' = W0 + s B A) is the DoRA gradient with the
+                # row gain g = m / ||W'|| == 1: magnitude and norm are both ones, the magnitude gradient is discarded
+                mag = nrm = torch.ones(mod.out_features, dtype=torch.float32, device=dev)
+                dm = torch.zeros_like(mag)
+                grads.append((rA, rB))
+            keep += [A, Bm, mag, nrm, dA, dB, dm]
             arr[i] = _lib.DoraTarget(li, pid, mod.r, float(mod.scaling), A.data_ptr(), Bm.data_ptr(), mag.data_ptr(),
                                      nrm.data_ptr(), dA.data_ptr(), dB.data_ptr(), dm.data_ptr())
         # gradient w.r.t. the input features (conv stem backward) only when autograd asks for it
@@ -102,8 +108,8 @@ class _EncoderTrain(torch.autograd.Function):
                                                    int(ctx.pooled), torch.cuda.current_stream().cuda_stream),
                   "gww_encoder_train_backward")
         flat = []
-        for dA, dB, dm in grads:
-            flat += [dA, dB, dm]
+        for g in grads:
+            flat += list(g)
         assert len(flat) == ctx.n_params
         ctx.ws = ctx.saved = None
         return (None, d_mel, None, *flat)
@@ -118,6 +124,7 @@ def encoder_train_forward(encoder, mel: torch.Tensor, pooled: bool = False) -> t
         raise _lib.GwwError("the training step is implemented for precision='bf16'")
     params = []
     for _, _, mod in dora_targets(encoder):
-        params += [mod.lora_A[mod.adapter].weight, mod.lora_B[mod.adapter].weight,
-                   mod.lora_magnitude_vector[mod.adapter].weight]
+        params += [mod.lora_A[mod.adapter].weight, mod.lora_B[mod.adapter].weight]
+        if mod.use_dora:
+            params.append(mod.lora_magnitude_vector[mod.adapter].weight)
     return _EncoderTrain.apply(encoder, mel, bool(pooled), *params)

@@ -19,7 +19,7 @@ Differences that come with the hardware path:
   * scalars go to ``<log-dir>/train_log.jsonl`` (TensorBoard is not installed);
   * under ``torchrun`` every rank trains on its shard of each epoch and the trainable gradients are all-reduced
     in ONE flat bucket (RCCL).
-Only ``--method DoRA`` (the reference default) has a HIP backward; LoRA / full_finetune raise.
+``--method DoRA`` (the reference default) and ``--method LoRA`` have a HIP backward; ``full_finetune`` raises.
 """
 import argparse
 import fnmatch
@@ -109,8 +109,10 @@ def main(args):
     patterns = ["layers.*.self_attn.q_proj", "layers.*.self_attn.k_proj", "layers.*.self_attn.v_proj",
                 "layers.*.self_attn.o_proj"]                          # src/train.py:232 (o_proj matches nothing in HF Whisper)
     matched = [m for p in patterns for m in fnmatch.filter(module_names, p)]
-    if args.method != "DoRA":
-        raise NotImplementedError("only --method DoRA has a HIP backward (LoRA / full_finetune are not built)")
+    if args.method not in ("DoRA", "LoRA"):
+        # src/train.py:244-250: full_finetune trains every base weight -- that needs weight-gradient GEMMs for all 40
+        # dense panels and the stem, which this hot path (frozen base) does not build
+        raise NotImplementedError("--method DoRA and LoRA have a HIP backward; full_finetune is out of scope (DESIGN.md section 6)")
     if args.load_model_path:
         # resume (src/train.py:44-60): the saved adapter is loaded onto the BARE encoder -- PeftModel.from_pretrained
         # wraps the nn.Linear targets itself -- and stays trainable
@@ -118,8 +120,8 @@ def main(args):
         peft = PeftModel.from_pretrained(encoder, os.path.join(args.load_model_path, args.load_lora_weights),
                                          is_trainable=True).to(device)
     else:
-        peft = get_peft_model(encoder, LoraConfig(use_dora=True, r=args.lora_rank, lora_alpha=args.lora_alpha,
-                                                  target_modules=matched)).to(device)
+        peft = get_peft_model(encoder, LoraConfig(use_dora=args.method == "DoRA", r=args.lora_rank,   # src/train.py:253, :263
+                                                  lora_alpha=args.lora_alpha, target_modules=matched)).to(device)
     for name, p in peft.named_parameters():
         p.requires_grad = "lora" in name
     model = two_channel_ligo_binary_classifier(peft).to(device)

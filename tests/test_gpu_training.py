@@ -235,6 +235,74 @@ def test_dora_parameter_gradients_fused_qkv(T, gww, d, M, np_):
         np.testing.assert_allclose(dm.cpu().numpy(), dm_ref, atol=2e-2 * np.abs(dm_ref).max(), rtol=2e-2)
 
 
+def test_lora_step_matches_finite_differences(T, gww):
+    """``--method LoRA`` of the reference (Signal_vs_Noise/src/train.py:251-258: ``LoraConfig(use_dora=False)``): the
+    same HIP backward with the row gain fixed at one.  W' = W0 + s B A, gradients of A and B against central finite
+    differences of the fp64 oracle forward (aligned and random directions, tolerance 3 % as for DoRA), both forms of
+    the step; no magnitude parameter exists."""
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    from gw_whisper_amd.peft import LoraConfig, get_peft_model
+    d, L, H, F = synth.ENCODER_SIZES["micro"]
+    cfg = oenc.EncCfg(d, L, H, F)
+    sd = synth.encoder_state_dict(d, L, H, F, seed=3)
+    mel = olm.log_mel(synth.strain_segments(2, seed=33))
+    enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig(d, L, H, F), precision="bf16")
+    targets = [f"layers.{i}.self_attn.{p}" for i in range(L) for p in ("q_proj", "k_proj", "v_proj")]
+    peft = get_peft_model(enc, LoraConfig(use_dora=False, r=8, lora_alpha=32, target_modules=targets)).cuda()
+    theta = {}
+    with T.no_grad():
+        for j, name in enumerate(targets):
+            lin = peft.base_model.model.get_submodule(name)
+            assert len(lin.lora_magnitude_vector) == 0
+            A, Bm, _ = synth.dora_adapter(d, d, 8, sd[name + ".weight"], seed=70 + j)
+            lin.lora_A["default"].weight.copy_(T.from_numpy(A))
+            lin.lora_B["default"].weight.copy_(T.from_numpy(Bm))
+            theta[name] = [A.astype(np.float64), Bm.astype(np.float64)]
+    wloss = np.random.default_rng(0).standard_normal((2, d))
+    grads, losses = {}, {}
+    for mode in ("hidden", "last_token"):
+        for p in peft.parameters():
+            p.grad = None
+        last = peft.last_token(T.from_numpy(mel).cuda()) if mode == "last_token" else \
+            peft(T.from_numpy(mel).cuda()).last_hidden_state[:, -1, :]
+        loss = (last * T.from_numpy(wloss).cuda().float()).sum()
+        loss.backward()
+        losses[mode] = float(loss.detach())
+        grads[mode] = {n: [peft.base_model.model.get_submodule(n).lora_A["default"].weight.grad.double().cpu().numpy(),
+                           peft.base_model.model.get_submodule(n).lora_B["default"].weight.grad.double().cpu().numpy()]
+                       for n in targets}
+        assert all(np.isfinite(g).all() and np.abs(g).max() > 0 for gs in grads[mode].values() for g in gs)
+        assert all(p.grad is None for n, p in peft.named_parameters() if "lora_" not in n)
+
+    def loss_of(th):
+        sd2 = {k: v.astype(np.float64) for k, v in sd.items()}
+        for k, (A, Bm) in th.items():
+            sd2[k + ".weight"] = sd[k + ".weight"].astype(np.float64) + 4.0 * (Bm @ A)
+        return float((oenc.encoder_forward(sd2, mel, cfg, dtype=np.float64)[:, -1, :] * wloss).sum())
+
+    ref_loss = loss_of(theta)
+    for mode in grads:
+        assert abs(losses[mode] - ref_loss) < 3e-2 * max(1.0, abs(ref_loss)), (mode, losses[mode], ref_loss)
+    rng = np.random.default_rng(1)
+    gref = grads["last_token"]
+    for kind in ("random", "aligned"):
+        dirs = {}
+        for k, v in theta.items():
+            if kind == "random":
+                dirs[k] = [rng.standard_normal(a.shape) * np.sqrt(np.mean(a * a) + 1e-12) for a in v]
+            else:
+                dirs[k] = [g / (np.sqrt(np.mean(g * g)) + 1e-30) * np.sqrt(np.mean(a * a) + 1e-12) for g, a in zip(gref[k], v)]
+        eps = 1e-3
+        plus = {k: [a + eps * dd for a, dd in zip(v, dirs[k])] for k, v in theta.items()}
+        minus = {k: [a - eps * dd for a, dd in zip(v, dirs[k])] for k, v in theta.items()}
+        fd = (loss_of(plus) - loss_of(minus)) / (2 * eps)
+        for mode in grads:
+            an = sum(float((g * dd).sum()) for k in theta for g, dd in zip(grads[mode][k], dirs[k]))
+            scale = abs(fd) if kind == "aligned" else np.sqrt(sum(float(((g * dd) ** 2).sum()) for k in theta
+                                                                  for g, dd in zip(grads[mode][k], dirs[k])))
+            assert abs(an - fd) < 3e-2 * scale + 1e-6, (kind, mode, an, fd, scale)
+
+
 @pytest.mark.parametrize("projs", [("q_proj", "k_proj", "v_proj"), ("q_proj", "k_proj", "v_proj", "out_proj")],
                          ids=["qkv", "qkvo"])
 @pytest.mark.parametrize("enc_name", ["micro", "tiny"])
