@@ -42,36 +42,27 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #ifndef GWW_MF_OLDDMA
 #define GWW_MF_OLDDMA 0   // diagnostic: round 1's eight-instruction DMA issue
 #endif
-#ifndef GWW_MF_VG
-#define GWW_MF_VG 18   // VALU instructions scheduled behind each MFMA of a step that carries a GELU piece
-#endif
 #ifndef GWW_MF_AHEAD
-#define GWW_MF_AHEAD 3
+#define GWW_MF_AHEAD 3    // tiles in flight; 3 makes the ring four stages deep and every stage a compile-time constant
 #endif
 #ifndef GWW_MF_SCHED
-#define GWW_MF_SCHED 1  // 1: GELU instructions placed by hand into the MFMA gaps (gelu_slice + order fences: every gap then holds
-                        // one fragment read + four GELU instructions, checked in the ISA); 0: round 1's scheduler hints, which
-                        // hipcc turns into one ~30-instruction lump per four MFMAs.  MEASURED EQUAL (1.36 / 1.36 ms plain,
-                        // 1.74 / 1.72 ms with q/k/v, tools/mlp_exp.py, one process per build on one box): the kernel's time
-                        // follows the NUMBER of instructions it executes, not their placement -- the chip holds ~1.35 GHz
-                        // under this kernel (power), so a build without the GELU is 37 % faster, without the fragment reads
-                        // 21 %, without the DMA 6 %, wherever those instructions sit.
+#define GWW_MF_SCHED 1  // 1 (shipped): the GELU is placed by hand into the MFMA gaps, four values per gap (gelu_slice), every
+                        // main-loop MFMA is a volatile asm statement, the fc1 accumulators live in architectural registers
+                        // and start from the folded bias, W1' / W2 are packed x 1/8 / x 8.  0: round 1's form (builtin MFMAs,
+                        // scheduler hints that hipcc turns into one ~30-instruction lump per four MFMAs): 64.6 against 42.6
+                        // cycles per MFMA in the main loop (profiles/r02_mlp_phase_stamps.md).
 #endif
 #ifndef GWW_MF_VACC
 #define GWW_MF_VACC 1   // (with SCHED) fc1 accumulators in architectural registers, MFMAs as asm
 #endif
-#ifndef GWW_MF_AF_AGPR
-#define GWW_MF_AF_AGPR 0   // how many of the 24 A-operand fragments (4 registers each) are pinned to the accumulator file
-#endif
 #ifndef GWW_MF_DMAGAP
-#define GWW_MF_DMAGAP 1
+#define GWW_MF_DMAGAP 1   // (with SCHED) DMA pieces of a riding tile in the gaps the GELU schedule leaves empty (0: one per step)
 #endif
 #ifndef GWW_MF_NORM
 #define GWW_MF_NORM 1   // 1: the A operand is normalised once per panel, a^ = bf16((a - mean') rstd), so the fc1 / q,k,v outputs need
                         // only + cb (0: round 1's per-value LayerNorm algebra rstd (acc - mean' u) + cb: two more VALU
                         // instructions and an LDS read of u per activation value -- the GELU path is what bounds the main loop)
 #endif
-constexpr int MF_AF_AGPR = GWW_MF_AF_AGPR;
 constexpr int MF_AHEAD = GWW_MF_AHEAD;   // tiles in flight ahead of the one being computed
 // Ring: AHEAD + 1 slots of one 16-KiB tile, one s_barrier per tile.  (One barrier per two tiles with one more slot was
 // built and measured in round 2: 1.154 vs 1.159 ms plain, 1.653 vs 1.653 ms with q/k/v -- no gain, removed.)
@@ -432,10 +423,10 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   // dependent price and the loop ran no faster than the compiler's lumps.  This one works on FOUR values per gap -- a gap
   // holds the same operation on values 4 k, 4 k + 1 (pair A, operation j) and the previous operation on 4 k + 2, 4 k + 3
   // (pair B, operation j - 1): nothing in a gap depends on anything in the same or the previous gap's tail, and a gap
-  // never carries more than two transcendentals.  A phase has 3 tiles x 16 MFMAs = 48 gaps = 4 groups of 12; the 11
-  // operations of a value (bias add, x^2, clamp, two fma, x q, exp2, + 1, rcp, x s, pack) fill gaps 0 .. 10 (A) and
-  // 1 .. 11 (B).  The four bias values of group k + 1 are read from LDS in gap 6 of group k (group 0 of the NEXT phase in
-  // gap 42: phases advance through the folded-bias vector by 32 floats, so its address is this phase's + 32).
+  // never carries more than two transcendentals.  A phase has 3 tiles x 16 MFMAs = 48 gaps = 4 groups of 12; the 9
+  // operations of a value (clamp(S^2), two fma, S q, exp2, + 1, rcp, S s, pack -- no bias add, no v_min: see
+  // preload_bias and the S / 8 note in gelu_slice) fill gaps 0 .. 8 (A) and 1 .. 9 (B); gaps 9 .. 11 of every group
+  // are where the riding tile's DMA pieces go.
   float g_t[4] = {0.f, 0.f, 0.f, 0.f}, g_w[4] = {0.f, 0.f, 0.f, 0.f}, g_q[4] = {0.f, 0.f, 0.f, 0.f};
 #define MF_FENCE()                                                                                                       \
   asm volatile("" : "+v"(g_t[0]), "+v"(g_t[1]), "+v"(g_t[2]), "+v"(g_t[3]), "+v"(g_w[0]), "+v"(g_w[1]), "+v"(g_w[2]),   \
