@@ -102,6 +102,8 @@ SIGNATURES = {
     "gww_mlp_fused_bf16": (C.c_int, [C.c_void_p] * 8 + [C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_void_p]),
     "gww_mlp_pack_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gww_lnqkv_fused_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int,
+                                       C.c_void_p]),
     "gww_qscan_energy_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
                                        C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p]),
     "gww_qscan_interp_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,

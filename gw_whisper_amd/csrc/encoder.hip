@@ -35,6 +35,8 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
                      const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s,
                      const float* q_u = nullptr, const float* q_cb = nullptr, void* q_out = nullptr, int NQ = 0,
                      float* x_next_out = nullptr);
+int launch_lnqkv_fused(const float* x, const float* q_u, const float* q_cb, const void* Wt, void* q_out, long M, int d,
+                       int NQ, hipStream_t s);
 int launch_add_delta_f32(const float* x, const void* delta_bf16, float* out, long n, hipStream_t s);
 int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, long ldy, const float* bias_st,
                       float yscale, float scaling, const float* A, const float* Bm, const float* mag,
@@ -65,6 +67,7 @@ struct LayerW {
   // LayerNorm-folded panels for the A-stationary GEMMs (gain folded into W, see gemm_astat.hip)
   unsigned short *wqkv_ln, *w1_ln;
   unsigned short* wmlp;   // fused-MLP weight stream (d = 384): mlp_fused.hip
+  unsigned short* wqkv_st; // the folded q / k / v panel alone as a tile stream (layer 0: launch_lnqkv_fused)
   float *uqkv, *cbqkv, *u1, *cb1;
   // transposed bf16 panels [K][N] for the dX GEMMs of the training backward
   unsigned short *wqkvT, *woT, *w1T, *w2T;
@@ -122,7 +125,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
   const size_t o_c1b = take(d * 4), o_c2b = take(d * 4), o_pos = take((size_t)T * d * 4);
   const size_t o_lnw = take(d * 4), o_lnb = take(d * 4);
   struct LO { size_t wqkv, wo, w1, w2, wqkv32, wo32, w132, w232, bqkv, bqkv16, bo, b1, b2, ln1w, ln1b, ln2w, ln2b,
-                     wqkv_ln, w1_ln, uqkv, cbqkv, u1, cb1, wqkvT, woT, w1T, w2T, wmlp; };
+                     wqkv_ln, w1_ln, uqkv, cbqkv, u1, cb1, wqkvT, woT, w1T, w2T, wmlp, wqkv_st; };
   std::vector<LO> lo(L);
   for (int i = 0; i < L; ++i) {
     lo[i].wqkv = take((size_t)3 * d * d * 2);
@@ -145,6 +148,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
     lo[i].wqkv_ln = take((size_t)3 * d * d * 2);
     lo[i].w1_ln = take((size_t)F * d * 2);
     lo[i].wmlp = take(((size_t)2 * F * d + (size_t)3 * d * d) * 2);   // fc1' + fc2 (+ the next layer's q / k / v panel)
+    lo[i].wqkv_st = take(i == 0 ? (size_t)3 * d * d * 2 : 16);        // layer 0's own panel as a stream
     lo[i].uqkv = take(3 * d * 4);
     lo[i].cbqkv = take(3 * d * 4);
     lo[i].u1 = take(F * 4);
@@ -195,6 +199,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
     w.wqkv_ln = (unsigned short*)(p + lo[i].wqkv_ln);
     w.w1_ln = (unsigned short*)(p + lo[i].w1_ln);
     w.wmlp = (unsigned short*)(p + lo[i].wmlp);
+    w.wqkv_st = (unsigned short*)(p + lo[i].wqkv_st);
     w.uqkv = (float*)(p + lo[i].uqkv);
     w.cbqkv = (float*)(p + lo[i].cbqkv);
     w.u1 = (float*)(p + lo[i].u1);
@@ -350,6 +355,8 @@ static int pack_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_
       LayerW& w = e->layers[i];
       GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, i + 1 < n_layers ? e->layers[i + 1].wqkv_ln : nullptr, w.wmlp, d, F, 3 * d, s));
     }
+    if (!dirty || (dirty[0] & 1u))   // layer 0's folded q / k / v panel alone (no MLP in front of it)
+      GWW_TRY(launch_mlp_pack(nullptr, nullptr, e->layers[0].wqkv_ln, e->layers[0].wqkv_st, d, 0, 3 * d, s));
   }
   return GWW_OK;
 }
@@ -500,7 +507,7 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   GWW_HIP(hipMemsetAsync(c1, 0, (size_t)d * es, s));   // zero row 0 of batch 0 (token -1)
   // A-stationary kernels (A panel in registers, fused residual-add + LayerNorm prologue) for K = d <= 512
   // GWW_GENERIC_PATH (debug aid): bit 0 = generic layer GEMMs, bit 1 = generic conv1, bit 2 = generic conv2, bit 3 = unfused MLP,
-  // bit 4 = stand-alone QKV, bit 5 = no pooled last layer
+  // bit 4 = stand-alone QKV, bit 5 = no pooled last layer, bit 6 = layer 0's LN1 + QKV by the LN-fused A-stationary GEMM
   static const int generic_mask = getenv("GWW_GENERIC_PATH") ? atoi(getenv("GWW_GENERIC_PATH")) : 0;
   const bool astat = bf && (d == 384 || d == 512) && F % 128 == 0 && !(generic_mask & 1);
   const bool mlp_fused = astat && d == 384 && F <= 1536 && !(generic_mask & 8);   // bit 3 = separate fc1 / fc2 kernels
@@ -531,9 +538,14 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
     for (int i = 0; i < e->cfg.n_layers; ++i) {
       const LayerW& L = e->layers[i];
       if (!qkv_done) {
-        TR(TR_QKV, launch_gemm_astat(xc, d, pending, pending ? xn : nullptr, L.uqkv, L.cbqkv, L.wqkv_ln, nullptr, qkv, M,
-                                     3 * d, d, EPI_BIAS, 0, s));
-        if (pending) { float* t = xc; xc = xn; xn = t; }
+        if (i == 0 && !pending && fuse_qkv && !(generic_mask & 64)) {
+          // layer 0 (no delta pending behind the conv stem): the fused kernel's panel prologue + q / k / v tail
+          TR(TR_QKV, launch_lnqkv_fused(xc, L.uqkv, L.cbqkv, L.wqkv_st, qkv, M, d, 3 * d, s));
+        } else {
+          TR(TR_QKV, launch_gemm_astat(xc, d, pending, pending ? xn : nullptr, L.uqkv, L.cbqkv, L.wqkv_ln, nullptr, qkv, M,
+                                       3 * d, d, EPI_BIAS, 0, s));
+          if (pending) { float* t = xc; xc = xn; xn = t; }
+        }
       }
       qkv_done = false;
       if (i == 0 && skew_event) GWW_HIP(hipEventRecord(skew_event, s));   // the other half batch starts here

@@ -139,7 +139,11 @@ __device__ unsigned long long g_stamp_mlp[24];
 // while the output is still in registers; the 192 output-accumulator registers are free by then), whose weight
 // tiles simply continue the same stream.  The standalone LN+QKV kernel's 10 B/element HBM round trip of the
 // residual stream disappears.
-template <bool QKV>
+// MODE 0: the MLP block.  MODE 1: + the next layer's LN1 + q / k / v (QKV).  MODE 2 (LNQ): ONLY LayerNorm + q / k / v of a
+// residual stream that has no pending delta (layer 0, fed by the conv stem): the prologue without delta / store, then the
+// q / k / v tail on a stream that holds just those 54 tiles -- the panel prologue and the tail are the same code the
+// block kernel runs, instead of the LN-fused A-stationary GEMM (which hipcc spills).
+template <int MODE>
 __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, const unsigned short* delta, float* x_out,
                                                             const float* __restrict__ ln_u,
                                                             const float* __restrict__ ln_cb,
@@ -151,6 +155,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
                                                             unsigned short* __restrict__ q_out, int NQ,
                                                             float* x_next) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[MF_LDS];
+  constexpr bool QKV = MODE >= 1, LNQ = MODE == 2;
   constexpr int MF_NST = MF_AHEAD + 1;
   float* lds_cb = reinterpret_cast<float*>(lds + MF_OFF_CB);
   float* lds_u = reinterpret_cast<float*>(lds + MF_OFF_U);
@@ -210,7 +215,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     lds_cb[i] = GWW_MF_SCHED ? ln_cb[i] * 0.125f : ln_cb[i];   // SCHED: the fc1 accumulators hold S / 8 (gelu_slice)
     lds_u[i] = ln_u[i];
   }
-  for (int i = tid; i < MF_D; i += MF_THREADS) lds_b2[i] = b2[i];
+  if (!LNQ)
+    for (int i = tid; i < MF_D; i += MF_THREADS) lds_b2[i] = b2[i];
   // De-phase the first round of workgroups (later ones inherit the offsets as CUs free up): panels take
   // the same time everywhere, so without this every CU is in its HBM phase (prologue / epilogue) at the
   // same moment and idles HBM during the MFMA phase.
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       xrow[i] = X + grow[i] * MF_D + 4 * cchunk;
-      drow[i] = delta + grow[i] * MF_D + 4 * cchunk;
+      drow[i] = LNQ ? nullptr : delta + grow[i] * MF_D + 4 * cchunk;
     }
 #pragma unroll
     for (int S3 = 0; S3 < MF_KT; S3 += 3) {
@@ -262,8 +268,9 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           for (int i = 0; i < 4; ++i) {
             asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
                          : "=v"(xv[S][h2][i]) : "v"(xrow[i]), "n"((64 * (S3 + S) + 32 * h2) * 4) : "memory");
-            asm volatile("global_load_dwordx2 %0, %1, off offset:%2"
-                         : "=v"(dv[S][h2][i]) : "v"(drow[i]), "n"((64 * (S3 + S) + 32 * h2) * 2) : "memory");
+            if (!LNQ)
+              asm volatile("global_load_dwordx2 %0, %1, off offset:%2"
+                           : "=v"(dv[S][h2][i]) : "v"(drow[i]), "n"((64 * (S3 + S) + 32 * h2) * 2) : "memory");
           }
 #pragma unroll
       for (int Sl = 0; Sl < 3; ++Sl) {
@@ -272,14 +279,20 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xv[Sl][h2][i]), "+v"(dv[Sl][h2][i]) : "n"(46 - (8 * Sl + 4 * h2 + i)));
-            f32x4 v = xv[Sl][h2][i];
-            v[0] += bf2f((unsigned short)(dv[Sl][h2][i][0] & 0xffff));
-            v[1] += bf2f((unsigned short)(dv[Sl][h2][i][0] >> 16));
-            v[2] += bf2f((unsigned short)(dv[Sl][h2][i][1] & 0xffff));
-            v[3] += bf2f((unsigned short)(dv[Sl][h2][i][1] >> 16));
-            *reinterpret_cast<f32x4*>(x_out + grow[i] * MF_D + 64 * S + 32 * h2 + 4 * cchunk) = v;
-            asm volatile("" ::: "memory");   // keep the store count of the next wait exact
+            f32x4 v;
+            if (LNQ) {   // no delta, no write-back: load k of the batch of 24 is complete once 23 - k younger loads are outstanding
+              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xv[Sl][h2][i]) : "n"(23 - (8 * Sl + 4 * h2 + i)));
+              v = xv[Sl][h2][i];
+            } else {
+              asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xv[Sl][h2][i]), "+v"(dv[Sl][h2][i]) : "n"(46 - (8 * Sl + 4 * h2 + i)));
+              v = xv[Sl][h2][i];
+              v[0] += bf2f((unsigned short)(dv[Sl][h2][i][0] & 0xffff));
+              v[1] += bf2f((unsigned short)(dv[Sl][h2][i][0] >> 16));
+              v[2] += bf2f((unsigned short)(dv[Sl][h2][i][1] & 0xffff));
+              v[3] += bf2f((unsigned short)(dv[Sl][h2][i][1] >> 16));
+              *reinterpret_cast<f32x4*>(x_out + grow[i] * MF_D + 64 * S + 32 * h2 + 4 * cchunk) = v;
+              asm volatile("" ::: "memory");   // keep the store count of the next wait exact
+            }
             if (S == 0 && h2 == 0) {
               float t = (v[0] + v[1]) + (v[2] + v[3]);
               t += __shfl_xor(t, 1, 64);
@@ -489,9 +502,11 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   // W fragments are read one step ahead of their use, across tile boundaries too (the ring waits run one tile
   // ahead, so tile it + 1 is complete and visible while tile it is being computed).
   bf16x8 wf[2][4];
+  if (!LNQ) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
-    wf[0][t] = *reinterpret_cast<const bf16x8*>(lds + (t & 1) * 8192 + off1[t >> 1]);
+    for (int t = 0; t < 4; ++t)
+      wf[0][t] = *reinterpret_cast<const bf16x8*>(lds + (t & 1) * 8192 + off1[t >> 1]);
+  }
 
   const int nck = F / 64;                                             // 64-column chunks
   const int total = 6 * nck + (QKV ? (NQ / 128) * MF_KT : 0);         // tiles in the weight stream
@@ -639,6 +654,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   using I3 = std::integral_constant<int, 3>;
   using IM = std::integral_constant<int, -1>;
 
+  if constexpr (!LNQ) {   // ======== the MLP stream (MODE 2 has none: straight to the q / k / v tail)
   if (GWW_MF_SCHED) {   // bias of chunks 0 and 1 into S[0..1] and S[2..3] (later chunks: in the tiles marked below)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -692,6 +708,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     asm volatile("s_nop 15\n\ts_nop 15"
                  : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]), "+a"(oacc[3]), "+a"(oacc[4]), "+a"(oacc[5]), "+a"(oacc[6]),
                    "+a"(oacc[7]), "+a"(oacc[8]), "+a"(oacc[9]), "+a"(oacc[10]), "+a"(oacc[11]));
+  }   // ======== !LNQ
   if constexpr (!QKV) {
     mf_wait_vmcnt<0>();   // the re-reads issued past the end
     // ---- epilogue: + b2 -> bf16 -> wave-private LDS transpose -> whole-line stores
@@ -723,6 +740,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     // prologue), written to x_next (== x_out, i.e. IN PLACE, on the inference path; a buffer of its own on the training
     // path, which keeps x_new as x_mid), and shifted / measured / packed into the A fragments of k-tile np.
     // The tiles already in flight are older than these loads: hipcc's own vmcnt waits retire them first.
+    if constexpr (!LNQ) {   // the seam (MODE 2: the prologue already produced the normalised operand of LN1)
     {
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, cshift[4];
       // the x_new lines of three 64-column chunks are requested together (24 loads per lane; with the 192 output
@@ -839,6 +857,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #if GWW_MF_NORM
     normalise_af();
 #endif
+    }
     // u / cb of the QKV panel replace fc1's (every wave is past its last GELU piece: those end three tiles, i.e.
     // three barriers, before the loop exit)
     for (int i = tid; i < NQ; i += MF_THREADS) {
@@ -851,6 +870,10 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     MSTAMP(5);
     // ---- second GEMM: qkv[32 rows, NQ] = LN1(x_next) Wqkv'^T, n-tiles of 128 columns, 6 k-tiles each
     const int T0 = 6 * nck;
+    if (LNQ) {   // first-step fragments of the first tile (the MLP stream's last tile prefetches them otherwise)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wf[0][u] = *reinterpret_cast<const bf16x8*>(lds + stage * MF_TILE + u * 4096 + offq[0]);
+    }
     f32x16 acc[4];
     for (int nt = 0; nt < NQ / 128; ++nt) {
 #if GWW_MF_SCHED
@@ -1038,7 +1061,8 @@ __global__ __launch_bounds__(256) void k_mlp_pack(const unsigned short* __restri
 // 2 * 384 * F (+ NQ * 384) elements
 int launch_mlp_pack(const void* w1_folded, const void* w2, const void* wqkv_folded, void* out, int d, int F, int NQ,
                     hipStream_t s) {
-  GWW_REQUIRE(d == MF_D && F % 128 == 0 && F > 0, "mlp_pack: d must be 384 and ffn a multiple of 128");
+  GWW_REQUIRE(d == MF_D && F % 128 == 0 && F >= 0 && (F > 0 || wqkv_folded),
+              "mlp_pack: d must be 384 and ffn a multiple of 128 (0: only the q / k / v panel, for launch_lnqkv_fused)");
   GWW_REQUIRE(!wqkv_folded || (NQ > 0 && NQ % 128 == 0), "mlp_pack: the q / k / v panel needs NQ %% 128 == 0");
   const long n16 = (2L * MF_D * F + (wqkv_folded ? (long)NQ * MF_D : 0)) / 8;
   hipLaunchKernelGGL(k_mlp_pack, dim3((unsigned)cdiv(n16, 256)), dim3(256), 0, s, (const unsigned short*)w1_folded,
@@ -1074,11 +1098,30 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
   if (qkv) {
     float* xnx = x_next_out ? x_next_out : x_out;
     GWW_REQUIRE((((uintptr_t)xnx) & 15) == 0 && (const void*)xnx != (const void*)x, "mlp_fused: bad x_next_out");
-    GWW_MF_LAUNCH(true, q_u, q_cb, (unsigned short*)q_out, NQ, xnx);
+    GWW_MF_LAUNCH(1, q_u, q_cb, (unsigned short*)q_out, NQ, xnx);
   } else {
-    GWW_MF_LAUNCH(false, nullptr, nullptr, nullptr, 0, nullptr);
+    GWW_MF_LAUNCH(0, nullptr, nullptr, nullptr, 0, nullptr);
   }
 #undef GWW_MF_LAUNCH
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+// LayerNorm + q / k / v projection of a residual stream WITHOUT a pending delta (layer 0): q_out bf16 [>= roundup(M, 128),
+// NQ] = LN(x) Wqkv'^T + cb with the LayerNorm folded into Wt = launch_mlp_pack(NULL, NULL, wqkv_folded, ., 384, 0, NQ)
+// and q_u / q_cb (gww_ln_fold_weights).  x is only read.
+int launch_lnqkv_fused(const float* x, const float* q_u, const float* q_cb, const void* Wt, void* q_out, long M, int d,
+                       int NQ, hipStream_t s) {
+  GWW_REQUIRE(x && q_u && q_cb && Wt && q_out, "lnqkv_fused: NULL operand");
+  GWW_REQUIRE(d == MF_D, "lnqkv_fused: built for d_model = 384 (got %d)", d);
+  GWW_REQUIRE(NQ > 0 && NQ % 128 == 0 && NQ <= MF_FMAX, "lnqkv_fused: NQ = %d must be a multiple of 128, <= 1536", NQ);
+  GWW_REQUIRE(((((uintptr_t)x) | ((uintptr_t)Wt) | ((uintptr_t)q_out)) & 15) == 0, "lnqkv_fused: operands must be 16-byte aligned");
+  if (M == 0) return GWW_OK;
+  const long panels = cdiv(M, MF_BM);
+  hipLaunchKernelGGL((k_mlp_fused<2>), dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)nullptr,
+                     (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const unsigned short*)Wt,
+                     (const float*)nullptr, (unsigned short*)nullptr, M, 0, 0, q_u, q_cb, (unsigned short*)q_out, NQ,
+                     (float*)nullptr);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }
@@ -1100,8 +1143,13 @@ extern "C" int gww_debug_stamps_mlp(unsigned long long* out8, int reset) {
 
 extern "C" int gww_mlp_pack_bf16(const void* w1_folded, const void* w2, const void* wqkv_folded_or_null, void* out, int d,
                                  int F, int NQ, void* stream) {
-  GWW_REQUIRE(w1_folded && w2 && out, "gww_mlp_pack_bf16: NULL argument");
+  GWW_REQUIRE(out && ((w1_folded && w2) || (F == 0 && wqkv_folded_or_null)), "gww_mlp_pack_bf16: NULL argument");
   return launch_mlp_pack(w1_folded, w2, wqkv_folded_or_null, out, d, F, NQ, (hipStream_t)stream);
+}
+
+extern "C" int gww_lnqkv_fused_bf16(const float* x, const float* qkv_u, const float* qkv_cb, const void* Wt, void* qkv_out,
+                                    long M, int d, int NQ, void* stream) {
+  return launch_lnqkv_fused(x, qkv_u, qkv_cb, Wt, qkv_out, M, d, NQ, (hipStream_t)stream);
 }
 
 extern "C" int gww_mlp_fused_bf16(const float* x, const void* delta, float* x_out, const float* ln_u,

@@ -166,16 +166,39 @@ def gemm_fulln(a: torch.Tensor, w: torch.Tensor, bias=None, epilogue: int = 0) -
 def mlp_pack(w1_folded: torch.Tensor, w2: torch.Tensor, wqkv_folded: torch.Tensor | None = None) -> torch.Tensor:
     """Weight stream of mlp_fused: folded fc1 panel [F, 384] + fc2 panel [384, F] (+ the next layer's folded
     q / k / v panel [NQ, 384]) -> bf16 [2 * 384 * F (+ NQ * 384)]."""
-    w1 = _dev(w1_folded, torch.bfloat16, "W1")
-    w2 = _dev(w2, torch.bfloat16, "W2")
     wq = _dev(wqkv_folded, torch.bfloat16, "Wqkv") if wqkv_folded is not None else None
-    F, d = w1.shape
+    if w1_folded is None:            # only the q / k / v panel: the stream of lnqkv_fused
+        if wq is None:
+            raise _lib.GwwError("mlp_pack: nothing to pack")
+        w1 = w2 = None
+        F, d = 0, wq.shape[1]
+    else:
+        w1 = _dev(w1_folded, torch.bfloat16, "W1")
+        w2 = _dev(w2, torch.bfloat16, "W2")
+        F, d = w1.shape
     NQ = wq.shape[0] if wq is not None else 0
-    out = torch.empty((2 * d * F + NQ * d,), dtype=torch.bfloat16, device=w1.device)
-    with torch.cuda.device(w1.device):
-        check(lib().gww_mlp_pack_bf16(w1.data_ptr(), w2.data_ptr(), wq.data_ptr() if wq is not None else None,
-                                      out.data_ptr(), d, F, NQ, _stream()), "gww_mlp_pack_bf16")
+    dev = wq.device if w1 is None else w1.device
+    out = torch.empty((2 * d * F + NQ * d,), dtype=torch.bfloat16, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().gww_mlp_pack_bf16(w1.data_ptr() if w1 is not None else None, w2.data_ptr() if w2 is not None else None,
+                                      wq.data_ptr() if wq is not None else None, out.data_ptr(), d, F, NQ, _stream()),
+              "gww_mlp_pack_bf16")
     return out
+
+
+def lnqkv_fused(x, wt, qkv_u, qkv_cb):
+    """qkv bf16 [M, NQ] = LayerNorm(x) Wqkv'^T + cb for a residual stream without a pending delta (layer 0): the panel
+    prologue and the q / k / v tail of the fused MLP kernel; ``wt = mlp_pack(None, None, wqkv_folded)``."""
+    x = _dev(x, torch.float32, "x")
+    wt = _dev(wt, torch.bfloat16, "Wt")
+    M, d = x.shape
+    qu, qc = _dev(qkv_u, torch.float32), _dev(qkv_cb, torch.float32)
+    NQ = qu.numel()
+    qo = torch.empty(((M + 127) // 128 * 128, NQ), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().gww_lnqkv_fused_bf16(x.data_ptr(), qu.data_ptr(), qc.data_ptr(), wt.data_ptr(), qo.data_ptr(), M, d, NQ,
+                                         _stream()), "gww_lnqkv_fused_bf16")
+    return qo[:M]
 
 
 def mlp_fused(x, delta, wt, ln_u, ln_cb, b2, qkv=None):

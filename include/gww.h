@@ -244,6 +244,13 @@ int gww_mlp_fused_bf16(const float* x, const void* delta, float* x_out, const fl
  * sequence of swizzled 16-KiB LDS images the kernel streams. */
 int gww_mlp_pack_bf16(const void* w1_folded, const void* w2, const void* wqkv_folded_or_null, void* out, int d, int F,
                       int NQ, void* stream);
+/* self_attn_layer_norm + q / k / v projection of a residual stream with no pending delta (layer 0, fed by the conv stem;
+ * HF:modeling_whisper.py:392, 303-318) at d_model = 384, on the panel prologue and the q / k / v tail of
+ * gww_mlp_fused_bf16:  qkv_out bf16 [M (rows padded to 128), NQ] = LayerNorm(x) Wqkv'^T + cb.  x fp32 [M,384] is only read;
+ * qkv_u / qkv_cb from gww_ln_fold_weights; Wt = gww_mlp_pack_bf16(NULL, NULL, wqkv_folded, ., 384, 0, NQ).
+ * NQ % 128 == 0, NQ <= 1536. */
+int gww_lnqkv_fused_bf16(const float* x, const float* qkv_u, const float* qkv_cb, const void* Wt, void* qkv_out, long M,
+                         int d, int NQ, void* stream);
 /* Q-transform front end #2 (ml4gw QScan as used by MLGWSC-1/train.py:117-122,135-154; PARITY UNPINNED: ml4gw is not
  * vendored, pinned or installed -- the kernels follow oracle/qscan.py).  The host builds the static tiling once
  * (gw_whisper_amd/qscan.py): rows = int [n_rows][6] (plane, ntiles, windowsize, first data index, energy offset,

@@ -447,6 +447,34 @@ def test_mlp_pack_layout(T, gww):
                 np.testing.assert_array_equal(logical, 8 * w2n[128 * idx3 + row, 64 * cp:64 * cp + 64][sw])
 
 
+@pytest.mark.parametrize("M", [128, 1500, 777, 70000])
+def test_lnqkv_fused(T, gww, M):
+    """LayerNorm + q / k / v projection of a residual stream without a pending delta (layer 0) on the fused MLP kernel's
+    panel prologue and q / k / v tail (``gww_lnqkv_fused_bf16``) against fp64 LayerNorm + matmul; bf16 operand and
+    output rounding set the tolerance (the stand-alone LN-fused GEMM is held to the same one)."""
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(M)
+    d, NQ = 384, 1152
+    x = (rng.standard_normal((M, d)) * 2 + rng.standard_normal((M, 1)) * 3).astype(np.float32)
+    lw = (1 + 0.2 * rng.standard_normal(d)).astype(np.float32)
+    lb = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    wq = (rng.standard_normal((NQ, d)) / np.sqrt(d)).astype(np.float32)
+    bq = rng.standard_normal(NQ).astype(np.float32)
+    c = lambda a: T.from_numpy(np.asarray(a)).cuda()
+    wqf, uq, cq = ops.ln_fold_weights(c(wq), c(lw), c(lb), c(bq))
+    wt = ops.mlp_pack(None, None, wqf)
+    assert wt.numel() == NQ * d
+    x_dev = c(x)
+    got = ops.lnqkv_fused(x_dev, wt, uq, cq).float().cpu().numpy()
+    assert np.array_equal(x_dev.cpu().numpy(), x)                      # x is only read
+    x64 = x.astype(np.float64)
+    mu, var = x64.mean(1, keepdims=True), x64.var(1, keepdims=True)
+    ln = (x64 - mu) / np.sqrt(var + 1e-5) * lw + lb
+    ref = ln @ wq.astype(np.float64).T + bq
+    np.testing.assert_allclose(got, ref, atol=6e-2, rtol=2e-2)
+    assert np.abs(got - ref).mean() < 6e-3
+
+
 @pytest.mark.parametrize("M,F", [(128, 128), (1500, 1536), (777, 512), (4000, 1536), (70000, 1536)])
 def test_mlp_fused(T, gww, M, F):
     """LayerNorm -> fc1 -> GELU -> fc2 of (x + delta) in one kernel (mlp_fused.hip) against fp64:
