@@ -102,6 +102,9 @@ SIGNATURES = {
     "gww_mlp_fused_bf16": (C.c_int, [C.c_void_p] * 8 + [C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_void_p]),
     "gww_mlp_pack_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gww_attn_out_mlp_fused_bf16": (C.c_int, [C.c_void_p] * 9 + [C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int, C.c_void_p]),
+    "gww_mlp_pack_op_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gww_lnqkv_fused_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int,
                                        C.c_void_p]),
     "gww_qscan_energy_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,

@@ -30,11 +30,11 @@ int launch_stem_dz2(const void* dxb, const void* z2, void* out, int B, int T, in
 int launch_stem_dz1(const void* col, const void* z1, void* out, int B, int T, int Tin, int d, hipStream_t s);
 int launch_stem_dmel(const void* col1, float* dmel, int B, int Tin, int C, int Kp, hipStream_t s);
 int launch_mlp_pack(const void* w1_folded, const void* w2, const void* wqkv_folded, void* out, int d, int F, int NQ,
-                    hipStream_t s);
+                    hipStream_t s, const void* wo = nullptr);
 int launch_mlp_fused(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
                      const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s,
                      const float* q_u = nullptr, const float* q_cb = nullptr, void* q_out = nullptr, int NQ = 0,
-                     float* x_next_out = nullptr);
+                     float* x_next_out = nullptr, const float* bo = nullptr);
 int launch_lnqkv_fused(const float* x, const float* q_u, const float* q_cb, const void* Wt, void* q_out, long M, int d,
                        int NQ, hipStream_t s);
 int launch_add_delta_f32(const float* x, const void* delta_bf16, float* out, long n, hipStream_t s);
@@ -68,6 +68,7 @@ struct LayerW {
   unsigned short *wqkv_ln, *w1_ln;
   unsigned short* wmlp;   // fused-MLP weight stream (d = 384): mlp_fused.hip
   unsigned short* wqkv_st; // the folded q / k / v panel alone as a tile stream (layer 0: launch_lnqkv_fused)
+  unsigned short* wmlp_op; // the fused-MLP stream with the W_o tiles in front (inference: out_proj fused into the block)
   float *uqkv, *cbqkv, *u1, *cb1;
   // transposed bf16 panels [K][N] for the dX GEMMs of the training backward
   unsigned short *wqkvT, *woT, *w1T, *w2T;
@@ -125,7 +126,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
   const size_t o_c1b = take(d * 4), o_c2b = take(d * 4), o_pos = take((size_t)T * d * 4);
   const size_t o_lnw = take(d * 4), o_lnb = take(d * 4);
   struct LO { size_t wqkv, wo, w1, w2, wqkv32, wo32, w132, w232, bqkv, bqkv16, bo, b1, b2, ln1w, ln1b, ln2w, ln2b,
-                     wqkv_ln, w1_ln, uqkv, cbqkv, u1, cb1, wqkvT, woT, w1T, w2T, wmlp, wqkv_st; };
+                     wqkv_ln, w1_ln, uqkv, cbqkv, u1, cb1, wqkvT, woT, w1T, w2T, wmlp, wqkv_st, wmlp_op; };
   std::vector<LO> lo(L);
   for (int i = 0; i < L; ++i) {
     lo[i].wqkv = take((size_t)3 * d * d * 2);
@@ -149,6 +150,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
     lo[i].w1_ln = take((size_t)F * d * 2);
     lo[i].wmlp = take(((size_t)2 * F * d + (size_t)3 * d * d) * 2);   // fc1' + fc2 (+ the next layer's q / k / v panel)
     lo[i].wqkv_st = take(i == 0 ? (size_t)3 * d * d * 2 : 16);        // layer 0's own panel as a stream
+    lo[i].wmlp_op = take(((size_t)d * d + (size_t)2 * F * d + (size_t)3 * d * d) * 2);   // W_o + the stream above
     lo[i].uqkv = take(3 * d * 4);
     lo[i].cbqkv = take(3 * d * 4);
     lo[i].u1 = take(F * 4);
@@ -200,6 +202,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
     w.w1_ln = (unsigned short*)(p + lo[i].w1_ln);
     w.wmlp = (unsigned short*)(p + lo[i].wmlp);
     w.wqkv_st = (unsigned short*)(p + lo[i].wqkv_st);
+    w.wmlp_op = (unsigned short*)(p + lo[i].wmlp_op);
     w.uqkv = (float*)(p + lo[i].uqkv);
     w.cbqkv = (float*)(p + lo[i].cbqkv);
     w.u1 = (float*)(p + lo[i].u1);
@@ -351,9 +354,11 @@ static int pack_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_
   if (d == 384 && F % 128 == 0 && F <= 1536) {
     for (int i = 0; i < n_layers; ++i) {
       const unsigned m = dirty ? dirty[i] : 15u, mn = i + 1 < n_layers ? (dirty ? dirty[i + 1] : 15u) : 0u;
-      if (!(m & 12u) && !(mn & 1u)) continue;
+      if (!(m & 14u) && !(mn & 1u)) continue;   // (bit 1: out_proj, in front of the wmlp_op stream)
       LayerW& w = e->layers[i];
-      GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, i + 1 < n_layers ? e->layers[i + 1].wqkv_ln : nullptr, w.wmlp, d, F, 3 * d, s));
+      const void* wq_next = i + 1 < n_layers ? e->layers[i + 1].wqkv_ln : nullptr;
+      if ((m & 12u) || (mn & 1u)) GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, wq_next, w.wmlp, d, F, 3 * d, s));
+      GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, wq_next, w.wmlp_op, d, F, 3 * d, s, w.wo));
     }
     if (!dirty || (dirty[0] & 1u))   // layer 0's folded q / k / v panel alone (no MLP in front of it)
       GWW_TRY(launch_mlp_pack(nullptr, nullptr, e->layers[0].wqkv_ln, e->layers[0].wqkv_st, d, 0, 3 * d, s));
@@ -507,7 +512,7 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   GWW_HIP(hipMemsetAsync(c1, 0, (size_t)d * es, s));   // zero row 0 of batch 0 (token -1)
   // A-stationary kernels (A panel in registers, fused residual-add + LayerNorm prologue) for K = d <= 512
   // GWW_GENERIC_PATH (debug aid): bit 0 = generic layer GEMMs, bit 1 = generic conv1, bit 2 = generic conv2, bit 3 = unfused MLP,
-  // bit 4 = stand-alone QKV, bit 5 = no pooled last layer, bit 6 = layer 0's LN1 + QKV by the LN-fused A-stationary GEMM
+  // bit 4 = stand-alone QKV, bit 5 = no pooled last layer, bit 6 = layer 0's LN1 + QKV by the LN-fused A-stationary GEMM, bit 7 = stand-alone out_proj
   static const int generic_mask = getenv("GWW_GENERIC_PATH") ? atoi(getenv("GWW_GENERIC_PATH")) : 0;
   const bool astat = bf && (d == 384 || d == 512) && F % 128 == 0 && !(generic_mask & 1);
   const bool mlp_fused = astat && d == 384 && F <= 1536 && !(generic_mask & 8);   // bit 3 = separate fc1 / fc2 kernels
@@ -569,12 +574,16 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
         return GWW_OK;
       }
       TR(TR_ATTN, launch_attention_bf16(qkv, ctx, B, T, H, s, nullptr, false, q_log2));
-      TR(TR_OUT, launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, L.wo, L.bo, d1, M, d, d, EPI_BIAS, 0, s));
+      // out_proj fused in front of the MLP block (ctx is the A operand of a GEMM into the block's idle output
+      // accumulators; the bf16 delta never reaches HBM): needs no delta pending on xc, which holds on this path
+      const bool op = mlp_fused && fuse_qkv && !pending && !(generic_mask & 128);
+      if (!op)
+        TR(TR_OUT, launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, L.wo, L.bo, d1, M, d, d, EPI_BIAS, 0, s));
       if (mlp_fused && fuse_qkv && i + 1 < e->cfg.n_layers) {
         // ... and the next layer's LN1 + q / k / v projection appended: xn receives x_next (no delta pending)
         const LayerW& Ln = e->layers[i + 1];
-        TR(TR_MLPQKV, launch_mlp_fused(xc, d1, xn, L.u1, L.cb1, L.wmlp, L.b2, nullptr, M, d, F, s, Ln.uqkv, Ln.cbqkv, qkv,
-                                       3 * d));
+        TR(TR_MLPQKV, launch_mlp_fused(xc, op ? ctx : d1, xn, L.u1, L.cb1, op ? L.wmlp_op : L.wmlp, L.b2, nullptr, M, d, F, s,
+                                       Ln.uqkv, Ln.cbqkv, qkv, 3 * d, nullptr, op ? L.bo : nullptr));
         { float* t = xc; xc = xn; xn = t; }
         pending = nullptr;
         qkv_done = true;
@@ -582,7 +591,8 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
       }
       if (mlp_fused) {
         // LN2 + fc1 + GELU + fc2 in one kernel: the [M, ffn] activation never leaves the CU
-        TR(TR_MLP, launch_mlp_fused(xc, d1, xn, L.u1, L.cb1, L.wmlp, L.b2, d2, M, d, F, s));
+        TR(TR_MLP, launch_mlp_fused(xc, op ? ctx : d1, xn, L.u1, L.cb1, op ? L.wmlp_op : L.wmlp, L.b2, d2, M, d, F, s, nullptr,
+                                    nullptr, nullptr, 0, nullptr, op ? L.bo : nullptr));
         { float* t = xc; xc = xn; xn = t; }
       } else {
         TR(TR_FC1, launch_gemm_astat(xc, d, d1, xn, L.u1, L.cb1, L.w1_ln, nullptr, f1, M, F, d, EPI_GELU, 0, s));

@@ -74,7 +74,8 @@ constexpr int MF_SLICE_STRIDE = 144, MF_SLICE_BYTES = 32 * MF_SLICE_STRIDE;
 constexpr int MF_OFF_CB = MF_NST_MAX * MF_TILE;
 constexpr int MF_OFF_U = MF_OFF_CB + MF_FMAX * 4;
 constexpr int MF_OFF_B2 = MF_OFF_U + MF_FMAX * 4;
-constexpr int MF_OFF_SLICE = MF_OFF_B2 + MF_D * 4;
+constexpr int MF_OFF_BO = MF_OFF_B2 + MF_D * 4;     // out_proj bias (OP mode)
+constexpr int MF_OFF_SLICE = MF_OFF_BO + MF_D * 4;
 constexpr int MF_LDS = MF_OFF_SLICE + MF_WAVES * MF_SLICE_BYTES;
 static_assert(MF_LDS <= 160 * 1024, "LDS budget");
 
@@ -143,7 +144,11 @@ __device__ unsigned long long g_stamp_mlp[24];
 // residual stream that has no pending delta (layer 0, fed by the conv stem): the prologue without delta / store, then the
 // q / k / v tail on a stream that holds just those 54 tiles -- the panel prologue and the tail are the same code the
 // block kernel runs, instead of the LN-fused A-stationary GEMM (which hipcc spills).
-template <int MODE>
+// OP: the attention output projection is fused IN FRONT of the block: `delta` is then the attention context ctx (bf16
+// [M, 384]) and the stream starts with the 18 tiles of W_o; ctx is the A operand of a GEMM into the (still idle) output
+// accumulators, whose result + bo meets the residual stream in the seam code (x_new = x + bf16(ctx W_o^T + bo)).  The
+// stand-alone out_proj kernel and the bf16 delta round trip through HBM disappear.
+template <int MODE, bool OP>
 __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, const unsigned short* delta, float* x_out,
                                                             const float* __restrict__ ln_u,
                                                             const float* __restrict__ ln_cb,
@@ -153,13 +158,15 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
                                                             int stagger_ticks, const float* __restrict__ q_u,
                                                             const float* __restrict__ q_cb,
                                                             unsigned short* __restrict__ q_out, int NQ,
-                                                            float* x_next) {
+                                                            float* x_next, const float* __restrict__ bo) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[MF_LDS];
   constexpr bool QKV = MODE >= 1, LNQ = MODE == 2;
   constexpr int MF_NST = MF_AHEAD + 1;
   float* lds_cb = reinterpret_cast<float*>(lds + MF_OFF_CB);
   float* lds_u = reinterpret_cast<float*>(lds + MF_OFF_U);
   float* lds_b2 = reinterpret_cast<float*>(lds + MF_OFF_B2);
+  float* lds_bo = reinterpret_cast<float*>(lds + MF_OFF_BO);
+  constexpr int OP_TILES = OP ? 3 * MF_KT : 0;   // W_o tiles in front of the stream
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -217,6 +224,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   }
   if (!LNQ)
     for (int i = tid; i < MF_D; i += MF_THREADS) lds_b2[i] = b2[i];
+  if (OP)
+    for (int i = tid; i < MF_D; i += MF_THREADS) lds_bo[i] = bo[i];
   // De-phase the first round of workgroups (later ones inherit the offsets as CUs free up): panels take
   // the same time everywhere, so without this every CU is in its HBM phase (prologue / epilogue) at the
   // same moment and idles HBM during the MFMA phase.
@@ -242,6 +251,40 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     const long g = m_base + 8 * i + crow;
     grow[i] = g < M ? g : M - 1;
   }
+  if constexpr (OP) {
+    // ---- OP prologue: the attention context panel (bf16, read once in whole 128-byte lines: 8 bytes per lane) goes
+    // through the wave-private slice into the A fragments of the out_proj GEMM.  All 48 loads of a lane in flight at
+    // once (asm + counted waits, as below): load k is complete once 47 - k younger ones are outstanding.
+    const unsigned short* crow_p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) crow_p[i] = delta + grow[i] * MF_D + 4 * cchunk;
+    u32x2 cv[MF_KT][2][4];
+#pragma unroll
+    for (int S = 0; S < MF_KT; ++S)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          asm volatile("global_load_dwordx2 %0, %1, off offset:%2"
+                       : "=v"(cv[S][h2][i]) : "v"(crow_p[i]), "n"((64 * S + 32 * h2) * 2) : "memory");
+#pragma unroll
+    for (int S = 0; S < MF_KT; ++S) {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cv[S][h2][i]) : "n"(47 - (8 * S + 4 * h2 + i)));
+          *reinterpret_cast<u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8) = cv[S][h2][i];
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32x4 u = *reinterpret_cast<const u32x4*>(slice + r * MF_SLICE_STRIDE + (4 * hh + j) * 16);
+        asm volatile("" : "+v"(u)::"memory");
+        af[4 * S + j] = __builtin_bit_cast(bf16x8, u);
+      }
+    }
+    row_rstd = 1.f; row_mean = 0.f;   // set by the seam behind the out_proj GEMM
+  } else
   {
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, cshift[4];
     // All loads of three k-tiles (48 per lane, 144 registers) are issued before the first use -- two exposed
@@ -347,7 +390,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       af[i] = __builtin_bit_cast(bf16x8, w);
     }
   };
-  normalise_af();
+  if (!OP) normalise_af();   // (OP: after the seam that forms x_new)
 #endif
   MSTAMP(0);
 
@@ -502,14 +545,18 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   // W fragments are read one step ahead of their use, across tile boundaries too (the ring waits run one tile
   // ahead, so tile it + 1 is complete and visible while tile it is being computed).
   bf16x8 wf[2][4];
-  if (!LNQ) {
+  if (!LNQ && !OP) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
       wf[0][t] = *reinterpret_cast<const bf16x8*>(lds + (t & 1) * 8192 + off1[t >> 1]);
   }
+  if (OP) {   // first W_o tile ([128 n][64 k] image, the q / k / v tile format)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wf[0][u] = *reinterpret_cast<const bf16x8*>(lds + u * 4096 + offq[0]);
+  }
 
   const int nck = F / 64;                                             // 64-column chunks
-  const int total = 6 * nck + (QKV ? (NQ / 128) * MF_KT : 0);         // tiles in the weight stream
+  const int total = OP_TILES + 6 * nck + (QKV ? (NQ / 128) * MF_KT : 0);   // tiles in the weight stream
   int stage = 0;   // ring stage of the tile being computed
   int it = 0;      // flat index of the tile being computed
 
@@ -534,7 +581,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     // A four-stage ring makes the stage of every tile of the unrolled 12-tile body a compile-time constant (flat tile
     // index mod 4): every fragment address is then base register + immediate (no v_or_b32 per read: 8 cycles each
     // beside an MFMA, tools/ubench/mfma_gap.hip) and the DMA destination needs no wrap-around arithmetic.
-    constexpr int ST = MF_NST == 4 ? (decltype(flat_c)::value & 3) : -1;
+    constexpr int ST = MF_NST == 4 ? ((decltype(flat_c)::value + OP_TILES) & 3) : -1;
     if (ST >= 0) stage = ST;
     if constexpr (!(GWW_MF_EXP & 64)) {   // (64: diagnostic, no ring wait / barrier -- only meaningful together with 1)
       mf_wait_vmcnt<MF_GL * (MF_AHEAD - 2)>();
@@ -654,6 +701,170 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   using I3 = std::integral_constant<int, 3>;
   using IM = std::integral_constant<int, -1>;
 
+  // ---- the seam: residual + bf16(accumulated output + bias) -> new residual stream, LayerNorm statistics, A fragments.
+  // Per 64-column chunk np the output tile (rounded to bf16 exactly like the stand-alone kernels' delta) goes through the
+  // wave-private slice into row order, new = src + it is formed from whole-line reads of src, written to dst and shifted /
+  // measured / packed into the A fragments of k-tile np.  Used behind fc2 (src = x_new, dst = x_next, bias = b2: the
+  // operand of the next layer's q / k / v) and -- OP mode -- behind the fused out_proj (src = x, dst = x_new, bias = bo:
+  // the operand of fc1).  The ring tiles in flight are older than these loads: hipcc's own vmcnt waits retire them first.
+  auto seam = [&](const float* seam_src, float* seam_dst, const float* seam_bias) {
+
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, cshift[4];
+      // the x_new lines of three 64-column chunks are requested together (24 loads per lane; with the 192 output
+      // accumulators still live there is room for no more) -- two exposed round trips instead of six; asm +
+      // hand-counted vmcnt as in the prologue
+      // (second batch parked in accumulator registers: by then the operand fragments fill the arch VGPRs and
+      //  hipcc would otherwise copy the just-requested registers away BEFORE the data has landed; half of the output
+      //  accumulators are free at that point)
+      f32x4 xn4[3][2][4], xa4[3][2][4];
+      const float* xrow2[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xrow2[i] = seam_src + grow[i] * MF_D + 4 * cchunk;
+#pragma unroll
+      for (int np = 0; np < MF_KT; ++np) {
+        if (np % 3 == 0) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                if (np == 0)
+                  asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
+                               : "=v"(xn4[q][h2][i]) : "v"(xrow2[i]), "n"((64 * (np + q) + 32 * h2) * 4) : "memory");
+                else
+                  asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
+                               : "=a"(xa4[q][h2][i]) : "v"(xrow2[i]), "n"((64 * (np + q) + 32 * h2) * 4) : "memory");
+              }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * np + tt;
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int nl = 32 * t + 8 * cc + 4 * hh;
+            const float4 bv = *reinterpret_cast<const float4*>(seam_bias + nl);
+            u32x2 o = {pack2bf(oacc[t][4 * cc] + bv.x, oacc[t][4 * cc + 1] + bv.y),
+                       pack2bf(oacc[t][4 * cc + 2] + bv.z, oacc[t][4 * cc + 3] + bv.w)};
+            *reinterpret_cast<u32x2*>(slice + r * MF_SLICE_STRIDE + (32 * tt + 8 * cc + 4 * hh) * 2) = o;
+          }
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            // load k = 8 (np % 3) + 4 h2 + i of the batch: at most the 23 - k younger loads may be outstanding
+            // (the x_next stores are issued only after the whole batch is consumed: the count stays exact
+            // whatever rows are masked)
+            f32x4 v;
+            if (np < 3) {
+              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xn4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
+              v = xn4[np % 3][h2][i];
+            } else {
+              asm volatile("s_waitcnt vmcnt(%1)" : "+a"(xa4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
+              v = xa4[np % 3][h2][i];
+            }
+            const u32x2 dv = *reinterpret_cast<const u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8);
+            v[0] += bf2f((unsigned short)(dv[0] & 0xffff));
+            v[1] += bf2f((unsigned short)(dv[0] >> 16));
+            v[2] += bf2f((unsigned short)(dv[1] & 0xffff));
+            v[3] += bf2f((unsigned short)(dv[1] >> 16));
+            // rows past M are clamped duplicates of row M - 1: only the real row may update in place
+            xn4[np % 3][h2][i] = v;      // x_next, stored once the batch is consumed
+            if (np == 0 && h2 == 0) {
+              float t = (v[0] + v[1]) + (v[2] + v[3]);
+              t += __shfl_xor(t, 1, 64);
+              t += __shfl_xor(t, 2, 64);
+              t += __shfl_xor(t, 4, 64);
+              cshift[i] = t * (1.0f / 32.0f);
+            }
+            v[0] -= cshift[i]; v[1] -= cshift[i]; v[2] -= cshift[i]; v[3] -= cshift[i];
+            s1[i] += (v[0] + v[1]) + (v[2] + v[3]);
+            s2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8) = o;
+          }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          u32x4 u = *reinterpret_cast<const u32x4*>(slice + r * MF_SLICE_STRIDE + (4 * hh + j) * 16);
+          asm volatile("" : "+v"(u)::"memory");
+          af[4 * np + j] = __builtin_bit_cast(bf16x8, u);
+        }
+        if (np % 3 == 2) {   // batch consumed: x_next of its three chunks back in place (real rows only: rows past M
+                             // are clamped duplicates of row M - 1 and must not touch it)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (m_base + 8 * i + crow < M)
+                  *reinterpret_cast<f32x4*>(seam_dst + grow[i] * MF_D + 64 * (np - 2 + q) + 32 * h2 + 4 * cchunk) = xn4[q][h2][i];
+          asm volatile("" ::: "memory");
+        }
+      }
+      float* stat = reinterpret_cast<float*>(slice);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a = s1[i], b = s2[i];
+        a += __shfl_xor(a, 1, 64); b += __shfl_xor(b, 1, 64);
+        a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64);
+        a += __shfl_xor(a, 4, 64); b += __shfl_xor(b, 4, 64);
+        const float mean = a * (1.0f / MF_D);
+        const float var = fmaxf(b * (1.0f / MF_D) - mean * mean, 0.f);
+        if (cchunk == 0) {
+          stat[8 * i + crow] = rsqrtf(var + 1e-5f);
+          stat[32 + 8 * i + crow] = mean;
+        }
+      }
+      row_rstd = stat[r];
+      row_mean = stat[32 + r];
+      asm volatile("" : "+v"(row_rstd), "+v"(row_mean)::"memory");
+      };
+  if constexpr (OP) {
+    // ======== out_proj in front of the block: O[n][m] = sum_k W_o[n][k] ctx[m][k], 3 n-tiles x 6 k-tiles of the q / k / v
+    // tile format, accumulated into the (zeroed, still idle) output accumulators O[4 nt + u]
+    static_assert(MF_NST == 4, "OP mode relies on the four-stage ring");
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+#pragma unroll
+      for (int kt = 0; kt < MF_KT; ++kt) {
+        const int itile = nt * MF_KT + kt;               // compile-time: the stage is static
+        mf_wait_vmcnt<MF_GL * (MF_AHEAD - 2)>();
+        __builtin_amdgcn_s_barrier();
+        const int st = itile & 3, st_next = (itile + 1) & 3, dma_st = (itile + MF_AHEAD) & 3;
+        const int dma_tile = itile + MF_AHEAD < total ? itile + MF_AHEAD : total - 1;
+        const bool last = itile == OP_TILES - 1;          // its last step prefetches the first fc1 tile's fragments
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const int q = 4 * kt + sub;
+          bf16x8(&cur)[4] = wf[q & 1];
+          bf16x8(&nxt)[4] = wf[(q + 1) & 1];
+          const unsigned char* Wn = lds + (sub == 3 ? st_next : st) * MF_TILE;
+          issue_piece(dma_tile, dma_st, sub);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(oacc[4 * nt + u]) : "v"(cur[u]), "v"(af[4 * kt + sub]));
+            const int off = (last && sub == 3) ? (u & 1) * 8192 + off1[u >> 1] : u * 4096 + offq[(sub + 1) & 3];
+            nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + off);
+          }
+        }
+      }
+    }
+    it = OP_TILES;
+    stage = OP_TILES & 3;
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]), "+a"(oacc[3]), "+a"(oacc[4]), "+a"(oacc[5]), "+a"(oacc[6]),
+                   "+a"(oacc[7]), "+a"(oacc[8]), "+a"(oacc[9]), "+a"(oacc[10]), "+a"(oacc[11]));
+    seam(X, x_out, lds_bo);     // x_new = x + bf16(ctx W_o^T + bo): written to x_out, LN2 statistics, A fragments
+#if GWW_MF_NORM
+    normalise_af();
+#endif
+#pragma unroll
+    for (int t = 0; t < MF_OT; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) oacc[t][j] = 0.f;   // fc2 accumulates from zero
+  }
   if constexpr (!LNQ) {   // ======== the MLP stream (MODE 2 has none: straight to the q / k / v tail)
   if (GWW_MF_SCHED) {   // bias of chunks 0 and 1 into S[0..1] and S[2..3] (later chunks: in the tiles marked below)
 #pragma unroll
@@ -741,119 +952,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     // path, which keeps x_new as x_mid), and shifted / measured / packed into the A fragments of k-tile np.
     // The tiles already in flight are older than these loads: hipcc's own vmcnt waits retire them first.
     if constexpr (!LNQ) {   // the seam (MODE 2: the prologue already produced the normalised operand of LN1)
-    {
-      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, cshift[4];
-      // the x_new lines of three 64-column chunks are requested together (24 loads per lane; with the 192 output
-      // accumulators still live there is room for no more) -- two exposed round trips instead of six; asm +
-      // hand-counted vmcnt as in the prologue
-      // (second batch parked in accumulator registers: by then the operand fragments fill the arch VGPRs and
-      //  hipcc would otherwise copy the just-requested registers away BEFORE the data has landed; half of the output
-      //  accumulators are free at that point)
-      f32x4 xn4[3][2][4], xa4[3][2][4];
-      const float* xrow2[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xrow2[i] = x_out + grow[i] * MF_D + 4 * cchunk;
-#pragma unroll
-      for (int np = 0; np < MF_KT; ++np) {
-        if (np % 3 == 0) {
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                if (np == 0)
-                  asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
-                               : "=v"(xn4[q][h2][i]) : "v"(xrow2[i]), "n"((64 * (np + q) + 32 * h2) * 4) : "memory");
-                else
-                  asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
-                               : "=a"(xa4[q][h2][i]) : "v"(xrow2[i]), "n"((64 * (np + q) + 32 * h2) * 4) : "memory");
-              }
-        }
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const int t = 2 * np + tt;
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const int nl = 32 * t + 8 * cc + 4 * hh;
-            const float4 bv = *reinterpret_cast<const float4*>(lds_b2 + nl);
-            u32x2 o = {pack2bf(oacc[t][4 * cc] + bv.x, oacc[t][4 * cc + 1] + bv.y),
-                       pack2bf(oacc[t][4 * cc + 2] + bv.z, oacc[t][4 * cc + 3] + bv.w)};
-            *reinterpret_cast<u32x2*>(slice + r * MF_SLICE_STRIDE + (32 * tt + 8 * cc + 4 * hh) * 2) = o;
-          }
-        }
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            // load k = 8 (np % 3) + 4 h2 + i of the batch: at most the 23 - k younger loads may be outstanding
-            // (the x_next stores are issued only after the whole batch is consumed: the count stays exact
-            // whatever rows are masked)
-            f32x4 v;
-            if (np < 3) {
-              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xn4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
-              v = xn4[np % 3][h2][i];
-            } else {
-              asm volatile("s_waitcnt vmcnt(%1)" : "+a"(xa4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
-              v = xa4[np % 3][h2][i];
-            }
-            const u32x2 dv = *reinterpret_cast<const u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8);
-            v[0] += bf2f((unsigned short)(dv[0] & 0xffff));
-            v[1] += bf2f((unsigned short)(dv[0] >> 16));
-            v[2] += bf2f((unsigned short)(dv[1] & 0xffff));
-            v[3] += bf2f((unsigned short)(dv[1] >> 16));
-            // rows past M are clamped duplicates of row M - 1: only the real row may update in place
-            xn4[np % 3][h2][i] = v;      // x_next, stored once the batch is consumed
-            if (np == 0 && h2 == 0) {
-              float t = (v[0] + v[1]) + (v[2] + v[3]);
-              t += __shfl_xor(t, 1, 64);
-              t += __shfl_xor(t, 2, 64);
-              t += __shfl_xor(t, 4, 64);
-              cshift[i] = t * (1.0f / 32.0f);
-            }
-            v[0] -= cshift[i]; v[1] -= cshift[i]; v[2] -= cshift[i]; v[3] -= cshift[i];
-            s1[i] += (v[0] + v[1]) + (v[2] + v[3]);
-            s2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-            u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8) = o;
-          }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          u32x4 u = *reinterpret_cast<const u32x4*>(slice + r * MF_SLICE_STRIDE + (4 * hh + j) * 16);
-          asm volatile("" : "+v"(u)::"memory");
-          af[4 * np + j] = __builtin_bit_cast(bf16x8, u);
-        }
-        if (np % 3 == 2) {   // batch consumed: x_next of its three chunks back in place (real rows only: rows past M
-                             // are clamped duplicates of row M - 1 and must not touch it)
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-                if (m_base + 8 * i + crow < M)
-                  *reinterpret_cast<f32x4*>(x_next + grow[i] * MF_D + 64 * (np - 2 + q) + 32 * h2 + 4 * cchunk) = xn4[q][h2][i];
-          asm volatile("" ::: "memory");
-        }
-      }
-      float* stat = reinterpret_cast<float*>(slice);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float a = s1[i], b = s2[i];
-        a += __shfl_xor(a, 1, 64); b += __shfl_xor(b, 1, 64);
-        a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64);
-        a += __shfl_xor(a, 4, 64); b += __shfl_xor(b, 4, 64);
-        const float mean = a * (1.0f / MF_D);
-        const float var = fmaxf(b * (1.0f / MF_D) - mean * mean, 0.f);
-        if (cchunk == 0) {
-          stat[8 * i + crow] = rsqrtf(var + 1e-5f);
-          stat[32 + 8 * i + crow] = mean;
-        }
-      }
-      row_rstd = stat[r];
-      row_mean = stat[32 + r];
-      asm volatile("" : "+v"(row_rstd), "+v"(row_mean)::"memory");
-    }
+      seam(x_out, x_next, lds_b2);
 #if GWW_MF_NORM
     normalise_af();
 #endif
@@ -869,7 +968,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 
     MSTAMP(5);
     // ---- second GEMM: qkv[32 rows, NQ] = LN1(x_next) Wqkv'^T, n-tiles of 128 columns, 6 k-tiles each
-    const int T0 = 6 * nck;
+    const int T0 = OP_TILES + 6 * nck;
     if (LNQ) {   // first-step fragments of the first tile (the MLP stream's last tile prefetches them otherwise)
 #pragma unroll
       for (int u = 0; u < 4; ++u) wf[0][u] = *reinterpret_cast<const bf16x8*>(lds + stage * MF_TILE + u * 4096 + offq[0]);
@@ -1014,13 +1113,19 @@ __device__ __forceinline__ u32x4 mf_scale_bf16x8(u32x4 v, float f) {
 __global__ __launch_bounds__(256) void k_mlp_pack(const unsigned short* __restrict__ w1,
                                                   const unsigned short* __restrict__ w2,
                                                   const unsigned short* __restrict__ wq,
-                                                  unsigned short* __restrict__ out, int F, long n_chunks16) {
-  const int nck = F / 64, mlp_tiles = 6 * nck;
+                                                  unsigned short* __restrict__ out, int F, long n_chunks16,
+                                                  const unsigned short* __restrict__ wo) {
+  const int nck = F / 64, mlp_tiles = 6 * nck, op_tiles = wo ? 3 * MF_KT : 0;
   for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < n_chunks16; g += (long)gridDim.x * 256) {
-    const int tile = (int)(g >> 10), within = (int)(g & 1023);
+    const int tile_all = (int)(g >> 10), within = (int)(g & 1023);
     const int row = within >> 3, chunk = (within & 7) ^ ((row >> 1) & 7);
+    const int tile = tile_all - op_tiles;
     u32x4 v;
-    if (tile >= mlp_tiles) {
+    if (tile < 0) {
+      // W_o [384, 384] in front of the stream (OP mode): n-tile major, 6 k-tiles each, [128 n][64 k] images
+      const int nt = tile_all / MF_KT, kt = tile_all - nt * MF_KT;
+      v = *reinterpret_cast<const u32x4*>(wo + (long)(128 * nt + row) * MF_D + 64 * kt + 8 * chunk);
+    } else if (tile >= mlp_tiles) {
       // appended LN1-folded q / k / v panel [NQ, 384]: n-tile major, 6 k-tiles each, [128 n][64 k] images
       const int it2 = tile - mlp_tiles, nt = it2 / MF_KT, kt = it2 - nt * MF_KT;
       v = *reinterpret_cast<const u32x4*>(wq + (long)(128 * nt + row) * MF_D + 64 * kt + 8 * chunk);
@@ -1060,13 +1165,15 @@ __global__ __launch_bounds__(256) void k_mlp_pack(const unsigned short* __restri
 // w1_folded bf16 [F, 384], w2 bf16 [384, F] (+ wqkv_folded bf16 [NQ, 384] or NULL) -> out bf16,
 // 2 * 384 * F (+ NQ * 384) elements
 int launch_mlp_pack(const void* w1_folded, const void* w2, const void* wqkv_folded, void* out, int d, int F, int NQ,
-                    hipStream_t s) {
+                    hipStream_t s, const void* wo) {
   GWW_REQUIRE(d == MF_D && F % 128 == 0 && F >= 0 && (F > 0 || wqkv_folded),
               "mlp_pack: d must be 384 and ffn a multiple of 128 (0: only the q / k / v panel, for launch_lnqkv_fused)");
   GWW_REQUIRE(!wqkv_folded || (NQ > 0 && NQ % 128 == 0), "mlp_pack: the q / k / v panel needs NQ %% 128 == 0");
-  const long n16 = (2L * MF_D * F + (wqkv_folded ? (long)NQ * MF_D : 0)) / 8;
+  GWW_REQUIRE(!wo || F > 0, "mlp_pack: an out_proj panel goes in front of an MLP stream");
+  const long n16 = ((wo ? (long)MF_D * MF_D : 0) + 2L * MF_D * F + (wqkv_folded ? (long)NQ * MF_D : 0)) / 8;
   hipLaunchKernelGGL(k_mlp_pack, dim3((unsigned)cdiv(n16, 256)), dim3(256), 0, s, (const unsigned short*)w1_folded,
-                     (const unsigned short*)w2, (const unsigned short*)wqkv_folded, (unsigned short*)out, F, n16);
+                     (const unsigned short*)w2, (const unsigned short*)wqkv_folded, (unsigned short*)out, F, n16,
+                     (const unsigned short*)wo);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }
@@ -1074,9 +1181,11 @@ int launch_mlp_pack(const void* w1_folded, const void* w2, const void* wqkv_fold
 // x fp32 [M, 384], delta bf16 [M, 384], x_out fp32 [M, 384] (!= x); Wt = launch_mlp_pack of the gain-folded fc1
 // panel and the fc2 panel, ln_u / ln_cb from gww_ln_fold_weights; C bf16 [>= roundup(M, 128), 384] (whole
 // 128-row panels are stored).
+// bo != NULL (OP): `delta` is the attention context ctx (bf16 [M, 384]) and Wt starts with the W_o tiles
+// (launch_mlp_pack(..., wo)): x_out = x + bf16(ctx W_o^T + bo), then the block as above.
 int launch_mlp_fused(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
                      const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s,
-                     const float* q_u, const float* q_cb, void* q_out, int NQ, float* x_next_out) {
+                     const float* q_u, const float* q_cb, void* q_out, int NQ, float* x_next_out, const float* bo) {
   GWW_REQUIRE(x && delta && x_out && ln_u && ln_cb && Wt && b2, "mlp_fused: NULL operand");
   GWW_REQUIRE(d == MF_D, "mlp_fused: built for d_model = 384 (got %d)", d);
   GWW_REQUIRE(F % 128 == 0 && F > 0 && F <= MF_FMAX, "mlp_fused: ffn = %d must be a multiple of 128, <= 1536", F);
@@ -1092,15 +1201,17 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
   // stagger only when there is more than one round of workgroups to keep de-phased; 100 MHz ticks
   static const int stagger_env = getenv("GWW_MLP_STAGGER") ? atoi(getenv("GWW_MLP_STAGGER")) : 0;
   const int stagger = panels >= 512 ? stagger_env : 0;
-#define GWW_MF_LAUNCH(QQ, ...)                                                                                          \
-  hipLaunchKernelGGL((k_mlp_fused<QQ>), dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta, \
-                     x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger, __VA_ARGS__)
+#define GWW_MF_LAUNCH(QQ, OO, ...)                                                                                        \
+  hipLaunchKernelGGL((k_mlp_fused<QQ, OO>), dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta, \
+                     x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger, __VA_ARGS__, bo)
   if (qkv) {
     float* xnx = x_next_out ? x_next_out : x_out;
     GWW_REQUIRE((((uintptr_t)xnx) & 15) == 0 && (const void*)xnx != (const void*)x, "mlp_fused: bad x_next_out");
-    GWW_MF_LAUNCH(1, q_u, q_cb, (unsigned short*)q_out, NQ, xnx);
+    if (bo) GWW_MF_LAUNCH(1, true, q_u, q_cb, (unsigned short*)q_out, NQ, xnx);
+    else GWW_MF_LAUNCH(1, false, q_u, q_cb, (unsigned short*)q_out, NQ, xnx);
   } else {
-    GWW_MF_LAUNCH(0, nullptr, nullptr, nullptr, 0, nullptr);
+    if (bo) GWW_MF_LAUNCH(0, true, nullptr, nullptr, nullptr, 0, nullptr);
+    else GWW_MF_LAUNCH(0, false, nullptr, nullptr, nullptr, 0, nullptr);
   }
 #undef GWW_MF_LAUNCH
   GWW_LAUNCH_CHECK();
@@ -1118,10 +1229,10 @@ int launch_lnqkv_fused(const float* x, const float* q_u, const float* q_cb, cons
   GWW_REQUIRE(((((uintptr_t)x) | ((uintptr_t)Wt) | ((uintptr_t)q_out)) & 15) == 0, "lnqkv_fused: operands must be 16-byte aligned");
   if (M == 0) return GWW_OK;
   const long panels = cdiv(M, MF_BM);
-  hipLaunchKernelGGL((k_mlp_fused<2>), dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)nullptr,
+  hipLaunchKernelGGL((k_mlp_fused<2, false>), dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)nullptr,
                      (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const unsigned short*)Wt,
                      (const float*)nullptr, (unsigned short*)nullptr, M, 0, 0, q_u, q_cb, (unsigned short*)q_out, NQ,
-                     (float*)nullptr);
+                     (float*)nullptr, (const float*)nullptr);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }
@@ -1144,7 +1255,22 @@ extern "C" int gww_debug_stamps_mlp(unsigned long long* out8, int reset) {
 extern "C" int gww_mlp_pack_bf16(const void* w1_folded, const void* w2, const void* wqkv_folded_or_null, void* out, int d,
                                  int F, int NQ, void* stream) {
   GWW_REQUIRE(out && ((w1_folded && w2) || (F == 0 && wqkv_folded_or_null)), "gww_mlp_pack_bf16: NULL argument");
-  return launch_mlp_pack(w1_folded, w2, wqkv_folded_or_null, out, d, F, NQ, (hipStream_t)stream);
+  return launch_mlp_pack(w1_folded, w2, wqkv_folded_or_null, out, d, F, NQ, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int gww_mlp_pack_op_bf16(const void* wo, const void* w1_folded, const void* w2, const void* wqkv_folded_or_null,
+                                    void* out, int d, int F, int NQ, void* stream) {
+  GWW_REQUIRE(wo && w1_folded && w2 && out, "gww_mlp_pack_op_bf16: NULL argument");
+  return launch_mlp_pack(w1_folded, w2, wqkv_folded_or_null, out, d, F, NQ, (hipStream_t)stream, wo);
+}
+
+extern "C" int gww_attn_out_mlp_fused_bf16(const float* x, const void* ctx, const float* bo, float* x_out, const float* ln_u,
+                                           const float* ln_cb, const void* Wt, const float* b2, void* C, long M, int d,
+                                           int F, const float* qkv_u, const float* qkv_cb, void* qkv_out, int NQ,
+                                           void* stream) {
+  GWW_REQUIRE(bo, "gww_attn_out_mlp_fused_bf16: NULL out_proj bias");
+  return launch_mlp_fused(x, ctx, x_out, ln_u, ln_cb, Wt, b2, C, M, d, F, (hipStream_t)stream, qkv_u, qkv_cb, qkv_out, NQ,
+                          nullptr, bo);
 }
 
 extern "C" int gww_lnqkv_fused_bf16(const float* x, const float* qkv_u, const float* qkv_cb, const void* Wt, void* qkv_out,
@@ -1157,5 +1283,5 @@ extern "C" int gww_mlp_fused_bf16(const float* x, const void* delta, float* x_ou
                                   int F, const float* qkv_u, const float* qkv_cb, void* qkv_out, int NQ,
                                   void* stream) {
   return launch_mlp_fused(x, delta, x_out, ln_u, ln_cb, Wt, b2, C, M, d, F, (hipStream_t)stream, qkv_u, qkv_cb, qkv_out,
-                          NQ, nullptr);
+                          NQ, nullptr, nullptr);
 }

@@ -186,6 +186,42 @@ def mlp_pack(w1_folded: torch.Tensor, w2: torch.Tensor, wqkv_folded: torch.Tenso
     return out
 
 
+def attn_out_mlp_fused(x, ctx, wo, bo, w1_folded, w2, ln_u, ln_cb, b2, qkv=None):
+    """The attention output projection fused in front of ``mlp_fused``: x_new = x + bf16(ctx Wo^T + bo), then the block.
+    ``qkv=(wqkv_folded, u, cb)`` appends the next layer's LN1 + q / k / v.  Returns (C or qkv, x_new or x_next)."""
+    x = _dev(x, torch.float32, "x")
+    ctx = _dev(ctx, torch.bfloat16, "ctx")
+    wo = _dev(wo, torch.bfloat16, "Wo")
+    w1 = _dev(w1_folded, torch.bfloat16, "W1")
+    w2 = _dev(w2, torch.bfloat16, "W2")
+    wq = _dev(qkv[0], torch.bfloat16, "Wqkv") if qkv is not None else None
+    F, d = w1.shape
+    NQ = wq.shape[0] if wq is not None else 0
+    M = x.shape[0]
+    Mp = (M + 127) // 128 * 128
+    f = lambda t: _dev(t, torch.float32)
+    bo, u, cb, b2 = f(bo), f(ln_u), f(ln_cb), f(b2)
+    wt = torch.empty((d * d + 2 * d * F + NQ * d,), dtype=torch.bfloat16, device=x.device)
+    x_out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib().gww_mlp_pack_op_bf16(wo.data_ptr(), w1.data_ptr(), w2.data_ptr(), wq.data_ptr() if wq is not None else None,
+                                         wt.data_ptr(), d, F, NQ, _stream()), "gww_mlp_pack_op_bf16")
+        if qkv is None:
+            out = torch.empty((Mp, d), dtype=torch.bfloat16, device=x.device)
+            qu = qc = None
+        else:
+            qu, qc = f(qkv[1]), f(qkv[2])
+            out = torch.empty((Mp, NQ), dtype=torch.bfloat16, device=x.device)
+        check(lib().gww_attn_out_mlp_fused_bf16(x.data_ptr(), ctx.data_ptr(), bo.data_ptr(), x_out.data_ptr(), u.data_ptr(),
+                                                cb.data_ptr(), wt.data_ptr(), b2.data_ptr(),
+                                                out.data_ptr() if qkv is None else None, M, d, F,
+                                                qu.data_ptr() if qu is not None else None,
+                                                qc.data_ptr() if qc is not None else None,
+                                                out.data_ptr() if qkv is not None else None, NQ, _stream()),
+              "gww_attn_out_mlp_fused_bf16")
+    return out[:M], x_out
+
+
 def lnqkv_fused(x, wt, qkv_u, qkv_cb):
     """qkv bf16 [M, NQ] = LayerNorm(x) Wqkv'^T + cb for a residual stream without a pending delta (layer 0): the panel
     prologue and the q / k / v tail of the fused MLP kernel; ``wt = mlp_pack(None, None, wqkv_folded)``."""

@@ -244,6 +244,15 @@ int gww_mlp_fused_bf16(const float* x, const void* delta, float* x_out, const fl
  * sequence of swizzled 16-KiB LDS images the kernel streams. */
 int gww_mlp_pack_bf16(const void* w1_folded, const void* w2, const void* wqkv_folded_or_null, void* out, int d, int F,
                       int NQ, void* stream);
+/* The attention output projection fused IN FRONT of gww_mlp_fused_bf16 (HF:modeling_whisper.py:353-356, 396-398): ctx bf16
+ * [M,384] is the attention context, x_out = x + bf16(ctx W_o^T + bo) (the value the stand-alone out_proj + deferred
+ * residual add produce), then the block as gww_mlp_fused_bf16 describes, incl. the optional q / k / v tail.  Wt =
+ * gww_mlp_pack_op_bf16: the 18 tiles of W_o bf16 [384,384] in front of the gww_mlp_pack_bf16 stream. */
+int gww_attn_out_mlp_fused_bf16(const float* x, const void* ctx, const float* bo, float* x_out, const float* ln_u,
+                                const float* ln_cb, const void* Wt, const float* b2, void* C, long M, int d, int F,
+                                const float* qkv_u, const float* qkv_cb, void* qkv_out, int NQ, void* stream);
+int gww_mlp_pack_op_bf16(const void* wo, const void* w1_folded, const void* w2, const void* wqkv_folded_or_null, void* out,
+                         int d, int F, int NQ, void* stream);
 /* self_attn_layer_norm + q / k / v projection of a residual stream with no pending delta (layer 0, fed by the conv stem;
  * HF:modeling_whisper.py:392, 303-318) at d_model = 384, on the panel prologue and the q / k / v tail of
  * gww_mlp_fused_bf16:  qkv_out bf16 [M (rows padded to 128), NQ] = LayerNorm(x) Wqkv'^T + cb.  x fp32 [M,384] is only read;

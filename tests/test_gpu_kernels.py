@@ -447,6 +447,58 @@ def test_mlp_pack_layout(T, gww):
                 np.testing.assert_array_equal(logical, 8 * w2n[128 * idx3 + row, 64 * cp:64 * cp + 64][sw])
 
 
+@pytest.mark.parametrize("with_qkv", [False, True], ids=["plain", "qkv"])
+@pytest.mark.parametrize("M", [128, 1500, 777, 70000])
+def test_attn_out_mlp_fused(T, gww, M, with_qkv):
+    """The attention output projection fused IN FRONT of the MLP block (``gww_attn_out_mlp_fused_bf16``): it must produce
+    what the unfused sequence produces -- out_proj as a stand-alone bf16 GEMM (delta rounded to bf16), the deferred
+    residual add and ``mlp_fused`` -- to the last bf16 rounding of the delta: x_new against x + bf16(ctx Wo^T + bo) in
+    fp64 (a delta element may round the other way: one bf16 ulp of the delta), outputs against the unfused kernels."""
+    from gw_whisper_amd import ops
+    d, F, NQ = 384, 1536, 1152
+    rng = np.random.default_rng(M + 5)
+    x = (rng.standard_normal((M, d)) * 2 + 0.3).astype(np.float32)
+    x[::7] += 25.0
+    ctx = _bf(rng.standard_normal((M, d)))
+    wo = _bf(rng.standard_normal((d, d)) / np.sqrt(d))
+    bo = rng.standard_normal(d).astype(np.float32)
+    g = lambda n: (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    sm = lambda n: (0.1 * rng.standard_normal(n)).astype(np.float32)
+    lw, lb, lw1, lb1 = g(d), sm(d), g(d), sm(d)
+    w1 = (rng.standard_normal((F, d)) / np.sqrt(d)).astype(np.float32)
+    b1 = rng.standard_normal(F).astype(np.float32)
+    w2 = (rng.standard_normal((d, F)) / np.sqrt(F)).astype(np.float32)
+    b2 = rng.standard_normal(d).astype(np.float32)
+    wq = (rng.standard_normal((NQ, d)) / np.sqrt(d)).astype(np.float32)
+    bq = rng.standard_normal(NQ).astype(np.float32)
+    c = lambda a: T.from_numpy(np.asarray(a)).cuda()
+    w1f, u, cb = ops.ln_fold_weights(c(w1), c(lw), c(lb), c(b1))
+    wqf, uq, cq = ops.ln_fold_weights(c(wq), c(lw1), c(lb1), c(bq))
+    got, got_x = ops.attn_out_mlp_fused(c(x), c(ctx).bfloat16(), c(wo).bfloat16(), c(bo), w1f, c(w2).bfloat16(), u, cb, c(b2),
+                                        qkv=(wqf, uq, cq) if with_qkv else None)
+    # the delta the stand-alone out_proj emits, in fp64 then bf16
+    delta = ctx.astype(np.float64) @ wo.astype(np.float64).T + bo
+    x_new_ref = x.astype(np.float64) + _bf(delta).astype(np.float64)
+    ulp = np.abs(delta) * 2.0 ** -7 + 1e-6
+    if not with_qkv:
+        assert (np.abs(got_x.cpu().numpy() - x_new_ref) <= ulp + 2e-5).all()
+        assert np.abs(got_x.cpu().numpy() - x_new_ref).mean() < 1e-4        # almost every element rounds the same way
+    # the unfused kernels on the same operands
+    delta_dev = ops.gemm_astat(c(ctx).bfloat16(), c(wo).bfloat16(), c(bo))[:M].contiguous()
+    if with_qkv:
+        wt = ops.mlp_pack(w1f, c(w2).bfloat16(), wqf)
+        ref, ref_x = ops.mlp_fused(c(x), delta_dev, wt, u, cb, c(b2), qkv=(uq, cq))
+    else:
+        wt = ops.mlp_pack(w1f, c(w2).bfloat16())
+        ref, ref_x = ops.mlp_fused(c(x), delta_dev, wt, u, cb, c(b2))
+    a, b = got.float().cpu().numpy(), ref.float().cpu().numpy()
+    # a delta element that rounds the other way moves LayerNorm's input by one bf16 ulp of the delta: outputs agree to a
+    # few bf16 ulps of themselves, the residual stream to that ulp
+    assert np.abs(got_x.cpu().numpy() - ref_x.cpu().numpy()).max() <= (np.abs(delta).max() * 2.0 ** -7 + 1e-3) * (2 if with_qkv else 1)
+    np.testing.assert_allclose(a, b, atol=6e-2, rtol=2 ** -6)
+    assert np.sqrt(((a - b) ** 2).mean()) < 8e-3
+
+
 @pytest.mark.parametrize("M", [128, 1500, 777, 70000])
 def test_lnqkv_fused(T, gww, M):
     """LayerNorm + q / k / v projection of a residual stream without a pending delta (layer 0) on the fused MLP kernel's
