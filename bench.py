@@ -471,6 +471,12 @@ def main():
                 # pmc_hbm_bytes / algorithmic bytes > 1)
                 "mlp_fused+next_ln_qkv": (B * (4 * T_TOK * d * ffn + 2 * T_TOK * d * 3 * d), M * d * 16),
             }
+            if not traced.get("out_proj", (0, 0))[1] and args.precision == "bf16" and d == 384:
+                # out_proj is fused in front of the MLP block (k_mlp_fused<., true>): its FLOPs and bytes belong to that
+                # launch -- ctx 2 B in instead of the bf16 delta (2 B), nothing else changes at the HBM boundary
+                op = B * 2 * T_TOK * d * d
+                for k in ("mlp_fused(ln+fc1+gelu+fc2)", "mlp_fused+next_ln_qkv"):
+                    work[k] = (work[k][0] + op, work[k][1])
             rows = []
             for name, (ms, cnt) in traced.items():
                 if cnt == 0:

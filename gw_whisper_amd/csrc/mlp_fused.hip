@@ -853,6 +853,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     }
     it = OP_TILES;
     stage = OP_TILES & 3;
+    TSTAMP(14);
     asm volatile("s_nop 15\n\ts_nop 15"
                  : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]), "+a"(oacc[3]), "+a"(oacc[4]), "+a"(oacc[5]), "+a"(oacc[6]),
                    "+a"(oacc[7]), "+a"(oacc[8]), "+a"(oacc[9]), "+a"(oacc[10]), "+a"(oacc[11]));
@@ -864,6 +865,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     for (int t = 0; t < MF_OT; ++t)
 #pragma unroll
       for (int j = 0; j < 16; ++j) oacc[t][j] = 0.f;   // fc2 accumulates from zero
+    TSTAMP(15);
   }
   if constexpr (!LNQ) {   // ======== the MLP stream (MODE 2 has none: straight to the q / k / v tail)
   if (GWW_MF_SCHED) {   // bias of chunks 0 and 1 into S[0..1] and S[2..3] (later chunks: in the tiles marked below)

@@ -35,7 +35,15 @@ if os.environ.get("GWW_STAMP_QKV") == "1":   # the variant with the next layer's
     wq_f, uq, cq = ops.ln_fold_weights(wq, lw, lb, bq)
     wtq = ops.mlp_pack(w1_f, w2, wq_f)
     fn = lambda: ops.mlp_fused(x, dl, wtq, u1, c1, b2, qkv=(uq, cq))
-names = ["prologue", "ring wait + barrier", "stage bookkeeping", "epilogue", "main loop (light mode)", "x_next + LN1 (q/k/v variant)", "q/k/v tail: ring wait + barrier", "q/k/v tail: tile MFMAs"] + ([f"parity {i // 6} {'fc1' if i % 6 < 3 else 'fc2'} tile {i % 3}" for i in range(12)] if os.environ.get("GWW_STAMP_MODE", "1") != "3" else ["prologue: loads + x_new + pack (since kernel start)", "prologue: row statistics", "prologue: normalise + offsets", "prologue: ring wait + barrier", "G1(0): three tiles", "open GELU of chunk 0", "-", "-", "-", "-", "-", "-"])
+if os.environ.get("GWW_STAMP_OP") == "1":   # out_proj fused in front (ctx instead of delta)
+    ctxb = (torch.randn(M, d, device=dev)).bfloat16()
+    wo = (torch.randn(d, d, device=dev) / d ** 0.5).bfloat16()
+    bo = torch.randn(d, device=dev)
+    if os.environ.get("GWW_STAMP_QKV") == "1":
+        fn = lambda: ops.attn_out_mlp_fused(x, ctxb, wo, bo, w1_f, w2, u1, c1, b2, qkv=(wq_f, uq, cq))
+    else:
+        fn = lambda: ops.attn_out_mlp_fused(x, ctxb, wo, bo, w1_f, w2, u1, c1, b2)
+names = ["prologue", "ring wait + barrier", "stage bookkeeping", "epilogue", "main loop (light mode)", "x_next + LN1 (q/k/v variant)", "q/k/v tail: ring wait + barrier", "q/k/v tail: tile MFMAs"] + ([f"parity {i // 6} {'fc1' if i % 6 < 3 else 'fc2'} tile {i % 3}" for i in range(12)] if os.environ.get("GWW_STAMP_MODE", "1") != "3" else ["prologue: loads + x_new + pack (since kernel start)", "prologue: row statistics", "prologue: normalise + offsets", "prologue: ring wait + barrier", "G1(0): three tiles", "open GELU of chunk 0", "OP: out_proj GEMM (18 tiles)", "OP: seam x_new + normalise + zero O", "-", "-", "-", "-"])
 fn(); torch.cuda.synchronize()
 buf = (C.c_ulonglong * 24)()
 lib.gww_debug_stamps_mlp(buf, 1)
