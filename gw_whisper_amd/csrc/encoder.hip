@@ -830,14 +830,22 @@ extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int b
         return GWW_OK;
       }
       GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s, lse, false, q_log2));
-      GWW_TRY(launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, W.wo, W.bo, d1, M, d, d, EPI_BIAS, 0, s));
+      // out_proj fused in front of the block as on the inference path: x_mid = x_in + bf16(ctx W_o^T + bo) comes out of
+      // the kernel's seam (the backward needs ctx and x_mid, never the delta)
+      static const bool op = !(getenv("GWW_GENERIC_PATH") && (atoi(getenv("GWW_GENERIC_PATH")) & 128));
+      if (!op)
+        GWW_TRY(launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, W.wo, W.bo, d1, M, d, d, EPI_BIAS, 0, s));
+      const void* a2 = op ? (const void*)ctx : (const void*)d1;
+      const void* st2 = op ? W.wmlp_op : W.wmlp;
+      const float* bo2 = op ? W.bo : nullptr;
       if (l + 1 < L) {
         const LayerW& Wn = e->layers[l + 1];
         void* qkv_n = sv + (size_t)(l + 1) * sl.layer_stride + sl.qkv;
-        GWW_TRY(launch_mlp_fused(x_in(l), d1, x_mid, W.u1, W.cb1, W.wmlp, W.b2, nullptr, M, d, F, s, Wn.uqkv, Wn.cbqkv, qkv_n,
-                                 3 * d, x_in(l + 1)));
+        GWW_TRY(launch_mlp_fused(x_in(l), a2, x_mid, W.u1, W.cb1, st2, W.b2, nullptr, M, d, F, s, Wn.uqkv, Wn.cbqkv, qkv_n,
+                                 3 * d, x_in(l + 1), bo2));
       } else {
-        GWW_TRY(launch_mlp_fused(x_in(l), d1, x_mid, W.u1, W.cb1, W.wmlp, W.b2, d2, M, d, F, s));
+        GWW_TRY(launch_mlp_fused(x_in(l), a2, x_mid, W.u1, W.cb1, st2, W.b2, d2, M, d, F, s, nullptr, nullptr, nullptr, 0,
+                                 nullptr, bo2));
         GWW_TRY(launch_add_delta_f32(x_mid, d2, x_in(L), M * d, s));
       }
     }
