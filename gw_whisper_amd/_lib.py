@@ -123,7 +123,7 @@ SIGNATURES = {
     "gww_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
 }
 
-ABI_VERSION = 101   # include/gww.h GWW_VERSION this binding was written against
+ABI_VERSION = 102   # include/gww.h GWW_VERSION this binding was written against
 
 _lib = None
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GWW_VERSION 101  /* 0.1.1: pooled training entry points, gww_dora_grads_multi, gww_attention_log2q_bf16 */
+#define GWW_VERSION 102  /* 0.1.2: + whitening kernels, gww_qadapter_tail_f32, gww_attention_bwd_log2q_bf16, gww_lnqkv_fused_bf16, gww_attn_out_mlp_fused_bf16, gww_mlp_pack_op_bf16; the gww_mlp_pack_bf16 stream carries W1 / 8 and 8 W2 */
 
 #define GWW_OK 0
 #define GWW_ERR_ARG (-1)      /* bad argument (shape, null pointer, unsupported size) */
