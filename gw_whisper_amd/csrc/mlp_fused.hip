@@ -255,30 +255,26 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     grow[i] = g < M ? g : M - 1;
   }
   if constexpr (OP) {
-    // ---- OP prologue: the attention context panel (bf16, read once in whole 128-byte lines: 8 bytes per lane) goes
-    // through the wave-private slice into the A fragments of the out_proj GEMM.  All 48 loads of a lane in flight at
-    // once (asm + counted waits, as below): load k is complete once 47 - k younger ones are outstanding.
+    // ---- OP prologue: the attention context panel (bf16, read once in whole 128-byte lines: 16 bytes per lane, 8 lanes
+    // per row of a 64-column k-tile) goes through the wave-private slice into the A fragments of the out_proj GEMM.  All
+    // 24 loads of a lane in flight at once (asm + counted waits, as below): load k is complete once 23 - k younger ones
+    // are outstanding.
     const unsigned short* crow_p[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) crow_p[i] = delta + grow[i] * MF_D + 4 * cchunk;
-    u32x2 cv[MF_KT][2][4];
+    for (int i = 0; i < 4; ++i) crow_p[i] = delta + grow[i] * MF_D + 8 * cchunk;
+    u32x4 cv[MF_KT][4];
 #pragma unroll
     for (int S = 0; S < MF_KT; ++S)
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          asm volatile("global_load_dwordx2 %0, %1, off offset:%2"
-                       : "=v"(cv[S][h2][i]) : "v"(crow_p[i]), "n"((64 * S + 32 * h2) * 2) : "memory");
+      for (int i = 0; i < 4; ++i)
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(cv[S][i]) : "v"(crow_p[i]), "n"(64 * S * 2) : "memory");
 #pragma unroll
     for (int S = 0; S < MF_KT; ++S) {
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cv[S][h2][i]) : "n"(47 - (8 * S + 4 * h2 + i)));
-          *reinterpret_cast<u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8) = cv[S][h2][i];
-        }
+      for (int i = 0; i < 4; ++i) {
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cv[S][i]) : "n"(23 - (4 * S + i)));
+        *reinterpret_cast<u32x4*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + cchunk * 16) = cv[S][i];
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         u32x4 u = *reinterpret_cast<const u32x4*>(slice + r * MF_SLICE_STRIDE + (4 * hh + j) * 16);
