@@ -1,0 +1,53 @@
+"""The build's ISA audits (``__graft_entry__.build()`` runs them on the generated mlp_fused.s) on synthetic listings:
+they must flag the hazards they exist for and stay quiet on clean code."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+HEAD = "_Z6kernelv:\n"
+TAIL = "\ts_endpgm\n"
+
+
+def _run(tool, body, tmp_path):
+    f = tmp_path / "k.s"
+    f.write_text(HEAD + body + TAIL)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(f), "kernel"], capture_output=True, text=True)
+    return r.returncode, r.stdout
+
+
+def _asm(line):
+    return "\t;;#ASMSTART\n\t" + line + "\n\t;;#ASMEND\n"
+
+
+def test_asm_mfma_audit_flags_a_register_copy_in_front_of_an_asm_mfma(tmp_path):
+    body = "\tv_accvgpr_mov_b32 a80, a32\n" + _asm("v_mfma_f32_32x32x16_bf16 a[80:95], v[54:57], v[162:165], a[80:95]")
+    rc, out = _run("audit_asm_mfma.py", body, tmp_path)
+    assert rc == 1 and "HAZARD" in out and "1 hazards" in out
+
+
+def test_asm_mfma_audit_accepts_two_wait_states(tmp_path):
+    body = "\tv_accvgpr_mov_b32 a80, a32\n" + _asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[80:95], v[54:57], v[162:165], a[80:95]")
+    rc, out = _run("audit_asm_mfma.py", body, tmp_path)
+    assert rc == 0 and "1 asm MFMAs, 0 hazards" in out
+
+
+def test_asm_mfma_audit_flags_an_early_read_of_the_result(tmp_path):
+    mf = _asm("v_mfma_f32_32x32x16_bf16 v[48:63], v[168:171], v[64:67], v[48:63]")
+    rc, out = _run("audit_asm_mfma.py", mf + "\tv_add_f32_e32 v1, v2, v3\n\tv_mul_f32_e32 v136, v48, v48\n", tmp_path)
+    assert rc == 1 and "reads the result of asm MFMA" in out
+    rc, out = _run("audit_asm_mfma.py", mf + "\ts_nop 10\n\tv_mul_f32_e32 v136, v48, v48\n", tmp_path)
+    assert rc == 0
+    # an MFMA in between occupies the pipe for its 8 passes
+    rc, out = _run("audit_asm_mfma.py", mf + _asm("v_mfma_f32_32x32x16_bf16 v[16:31], v[168:171], v[64:67], v[16:31]")
+                   + "\ts_nop 2\n\tv_mul_f32_e32 v136, v48, v48\n", tmp_path)
+    assert rc == 0
+
+
+def test_asm_load_audit_flags_a_touch_before_the_covering_wait(tmp_path):
+    ld = _asm("global_load_dwordx4 v[10:13], v[2:3], off offset:0")
+    rc, out = _run("audit_asm_loads.py", ld + "\tv_mov_b32_e32 v20, v10\n\ts_waitcnt vmcnt(0)\n", tmp_path)
+    assert rc == 1 and "HAZARD" in out
+    rc, out = _run("audit_asm_loads.py", ld + "\ts_waitcnt vmcnt(0)\n\tv_mov_b32_e32 v20, v10\n", tmp_path)
+    assert rc == 0 and "1 asm loads, 0 hazards" in out
