@@ -353,20 +353,41 @@ int launch_gemm_bf16(const void* A, long lda, const void* W, const float* bias, 
 template <typename OutT>
 __global__ __launch_bounds__(256) void k_mel_to_tokens(const float* __restrict__ mel, OutT* __restrict__ out,
                                                        int C, int T) {
-  __shared__ float tile[64][81];
+  __shared__ __attribute__((aligned(16))) float tile[64][84];   // 84: rows stay 16-byte aligned, 4-way-free column walks
   const int b = blockIdx.y, t0 = blockIdx.x * 64;
   const float* src = mel + (long)b * C * T;
-  for (int i = threadIdx.x; i < C * 64; i += 256) {
-    const int c = i >> 6, tt = i & 63;
-    tile[tt][c] = (t0 + tt < T) ? src[(long)c * T + t0 + tt] : 0.f;
+  // 16 bytes per lane on both sides when the shapes allow it (T % 4 == 0, C % 8 == 0: the Whisper front end's 3000 x 80):
+  // a lane reads four consecutive time samples of one mel bin and writes eight consecutive bins of one token
+  const bool vec = (T & 3) == 0 && (C & 7) == 0 && t0 + 64 <= T;
+  if (vec) {
+    for (int i = threadIdx.x; i < C * 16; i += 256) {
+      const int c = i >> 4, q = i & 15;
+      const float4 v = *reinterpret_cast<const float4*>(src + (long)c * T + t0 + 4 * q);
+      tile[4 * q][c] = v.x; tile[4 * q + 1][c] = v.y; tile[4 * q + 2][c] = v.z; tile[4 * q + 3][c] = v.w;
+    }
+  } else {
+    for (int i = threadIdx.x; i < C * 64; i += 256) {
+      const int c = i >> 6, tt = i & 63;
+      tile[tt][c] = (t0 + tt < T) ? src[(long)c * T + t0 + tt] : 0.f;
+    }
   }
   __syncthreads();
   OutT* dst = out + ((long)b * (T + 2) + 1 + t0) * C;
-  for (int i = threadIdx.x; i < 64 * C; i += 256) {
-    const int tt = i / C, c = i - tt * C;
-    if (t0 + tt < T) {
-      if constexpr (sizeof(OutT) == 2) dst[(long)tt * C + c] = f2bf(tile[tt][c]);
-      else dst[(long)tt * C + c] = tile[tt][c];
+  if (vec && sizeof(OutT) == 2) {
+    const int per_row = C >> 3;
+    for (int i = threadIdx.x; i < 64 * per_row; i += 256) {
+      const int tt = i / per_row, c = 8 * (i - tt * per_row);
+      const float4 lo = *reinterpret_cast<const float4*>(&tile[tt][c]), hi = *reinterpret_cast<const float4*>(&tile[tt][c + 4]);
+      u32x4 o = {pack2bf(lo.x, lo.y), pack2bf(lo.z, lo.w), pack2bf(hi.x, hi.y), pack2bf(hi.z, hi.w)};
+      *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(dst) + (long)tt * C + c) = o;
+    }
+  } else {
+    for (int i = threadIdx.x; i < 64 * C; i += 256) {
+      const int tt = i / C, c = i - tt * C;
+      if (t0 + tt < T) {
+        if constexpr (sizeof(OutT) == 2) dst[(long)tt * C + c] = f2bf(tile[tt][c]);
+        else dst[(long)tt * C + c] = tile[tt][c];
+      }
     }
   }
   if (blockIdx.x == 0) {
