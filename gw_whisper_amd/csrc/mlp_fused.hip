@@ -58,6 +58,14 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #ifndef GWW_MF_NTSTORE
 #define GWW_MF_NTSTORE 1   // q / k / v tail: non-temporal output stores (they retire sooner: the ring wait behind them is shorter, -2 % on the launch)
 #endif
+#ifndef GWW_MF_NTLOAD
+#define GWW_MF_NTLOAD 1   // streaming panel loads (x, delta / ctx, x_new) with the non-temporal hint
+#endif
+#if GWW_MF_NTLOAD
+#define MF_NT " nt"
+#else
+#define MF_NT ""
+#endif
 #ifndef GWW_MF_DMAGAP
 #define GWW_MF_DMAGAP 1   // (with SCHED) DMA pieces of a riding tile in the gaps the GELU schedule leaves empty (0: one per step)
 #endif
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     for (int S = 0; S < MF_KT; ++S)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(cv[S][i]) : "v"(crow_p[i]), "n"(64 * S * 2) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" MF_NT : "=v"(cv[S][i]) : "v"(crow_p[i]), "n"(64 * S * 2) : "memory");
 #pragma unroll
     for (int S = 0; S < MF_KT; ++S) {
 #pragma unroll
@@ -308,10 +316,10 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" MF_NT
                          : "=v"(xv[S][h2][i]) : "v"(xrow[i]), "n"((64 * (S3 + S) + 32 * h2) * 4) : "memory");
             if (!LNQ)
-              asm volatile("global_load_dwordx2 %0, %1, off offset:%2"
+              asm volatile("global_load_dwordx2 %0, %1, off offset:%2" MF_NT
                            : "=v"(dv[S][h2][i]) : "v"(drow[i]), "n"((64 * (S3 + S) + 32 * h2) * 2) : "memory");
           }
 #pragma unroll
@@ -729,10 +737,10 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 if (np == 0)
-                  asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
+                  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" MF_NT
                                : "=v"(xn4[q][h2][i]) : "v"(xrow2[i]), "n"((64 * (np + q) + 32 * h2) * 4) : "memory");
                 else
-                  asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
+                  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" MF_NT
                                : "=a"(xa4[q][h2][i]) : "v"(xrow2[i]), "n"((64 * (np + q) + 32 * h2) * 4) : "memory");
               }
         }
