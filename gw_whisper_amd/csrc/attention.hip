@@ -23,6 +23,9 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef GWW_ATT_EPI16
+#define GWW_ATT_EPI16 1   // context rows stored in 16-byte pieces (lane pairs exchange halves) instead of 8-byte ones
+#endif
 namespace gww {
 
 #ifdef GWW_STAMP
@@ -770,6 +773,29 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
   const float inv = 1.0f / l_tot;
   if (lse && q_row < T && hh == 0)
     lse[((long)b * H + h) * T + q_row] = (m_run + __log2f(l_tot)) * 0.69314718055994530942f;
+#if GWW_ATT_EPI16
+  {
+    // whole 16-byte row pieces: lanes l and l + 32 hold neighbouring 4-column groups of the same row, so one
+    // v_permlane32_swap per packed word hands the low lane columns 8 c .. 8 c + 7 of an even c and the high lane those of
+    // the odd c + 1 -- 4 stores of 16 bytes per lane instead of 8 of 8 bytes (the epilogue tail is store-issue bound)
+    unsigned short* orow = ctx + ((long)b * T + q_row) * d + h * DH;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        const int c0 = 2 * cp, c1 = 2 * cp + 1;
+        const unsigned a0 = pack2bf(ot[n][4 * c0] * inv, ot[n][4 * c0 + 1] * inv), a1 = pack2bf(ot[n][4 * c0 + 2] * inv, ot[n][4 * c0 + 3] * inv);
+        const unsigned b0 = pack2bf(ot[n][4 * c1] * inv, ot[n][4 * c1 + 1] * inv), b1 = pack2bf(ot[n][4 * c1 + 2] * inv, ot[n][4 * c1 + 3] * inv);
+        // swap(x, y): x's upper 32 lanes <-> y's lower 32 lanes
+        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        // low lanes: s?[0] = own group of c0, s?[1] = the partner's (hh = 1) group of c0; high lanes: s?[0] = the partner's
+        // (hh = 0) group of c1, s?[1] = own group of c1
+        u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+        if (q_row < T) *reinterpret_cast<u32x4*>(orow + 32 * n + 8 * (hh ? c1 : c0)) = o;
+      }
+  }
+#else
   if (q_row < T) {
     unsigned short* orow = ctx + ((long)b * T + q_row) * d + h * DH;
 #pragma unroll
@@ -782,6 +808,7 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
         *reinterpret_cast<u32x2*>(orow + dh) = o;
       }
   }
+#endif
 }
 
 // last_tile_only: compute only the query tile that holds token T - 1 (the other rows of ctx are left untouched) --
