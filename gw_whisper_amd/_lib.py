@@ -49,6 +49,7 @@ SIGNATURES = {
     "gww_frontend_destroy": (None, [C.c_void_p]),
     "gww_logmel_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
+    "gww_logmel_host_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_void_p]),
     "gww_encoder_create": (C.c_int, [C.POINTER(EncCfg), C.POINTER(C.c_void_p)]),
     "gww_encoder_destroy": (None, [C.c_void_p]),
     "gww_encoder_set_weights": (C.c_int, [C.c_void_p, C.POINTER(EncGlobals), C.POINTER(EncLayer),
@@ -123,7 +124,7 @@ SIGNATURES = {
     "gww_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
 }
 
-ABI_VERSION = 102   # include/gww.h GWW_VERSION this binding was written against
+ABI_VERSION = 103   # include/gww.h GWW_VERSION this binding was written against
 
 _lib = None
 

@@ -9,9 +9,17 @@ Mirrors the call surface the reference uses:
 Same argument meaning and error behaviour as HF
 (``HF:models/whisper/feature_extraction_whisper.py:193-346``): ``ValueError`` when
 ``sampling_rate != 16000``, zero-pad / truncate to 30 s, always returns a batch.
-The arithmetic runs on the GPU (``gww_logmel_f32``); there is no CPU fallback.  The
-result is returned on the CPU (like HF) unless ``return_device="cuda"``: the training
-harness keeps it on the GPU and skips the PCIe round trip.
+
+Two entry points of libgww.so do the arithmetic, chosen by ``device`` (constructor or call):
+
+* ``"cpu"`` -- the default, and what HF itself is: ``gww_logmel_host_f32``, plain C++ with no HIP call.  It is
+  fork-safe, so the reference's ``dataset.py`` works unchanged inside its forked ``DataLoader`` workers
+  (``Signal_vs_Noise/src/train.py:224-225``, ``--num_workers 12``);
+* ``"cuda"`` (or a CUDA tensor as input) -- the HIP kernels (``gww_logmel_f32``), the batched variant SURVEY.md
+  section 8b calls the additional entry point; ``return_device="cuda"`` keeps the features on the GPU and skips
+  the PCIe round trip.
+
+Neither is a fallback of the other and neither is torch / numpy: a missing ``libgww.so`` raises ``GwwError``.
 """
 
 from __future__ import annotations
@@ -36,7 +44,7 @@ class WhisperFeatureExtractor:
     model_input_names = ["input_features"]
 
     def __init__(self, feature_size=80, sampling_rate=16000, hop_length=160, chunk_length=30, n_fft=400,
-                 padding_value=0.0, device="cuda", **kwargs):
+                 padding_value=0.0, device="cpu", **kwargs):
         if (feature_size, sampling_rate, hop_length, chunk_length, n_fft) != (80, 16000, 160, 30, 400):
             raise ValueError("gw_whisper_amd implements the Whisper front end only for its published "
                              "configuration (80 mels, 16 kHz, hop 160, 30 s chunks, n_fft 400)")
@@ -65,7 +73,9 @@ class WhisperFeatureExtractor:
                 f" was sampled with {self.sampling_rate} and not {sampling_rate}.")
         if do_normalize or return_attention_mask or padding != "max_length" or max_length is not None:
             raise NotImplementedError("only the default padding='max_length' path the reference uses is implemented")
-        dev = torch.device(self.device if device in (None, "cpu") else device)
+        if device is None:
+            device = raw_speech.device if isinstance(raw_speech, torch.Tensor) and raw_speech.is_cuda else self.device
+        dev = torch.device(device)
         if isinstance(raw_speech, torch.Tensor):
             wave = raw_speech.to(dev, torch.float32)
             if wave.dim() == 1:
@@ -86,7 +96,7 @@ class WhisperFeatureExtractor:
                 m = min(len(r), n)
                 host[i, :m] = r[:m]
             wave = torch.from_numpy(host).to(dev)
-        feats = ops.logmel(wave)
+        feats = ops.logmel(wave) if dev.type == "cuda" else ops.logmel_host(wave)
         if return_device == "cpu":
             feats = feats.cpu()
         if return_tensors == "np":
@@ -95,4 +105,6 @@ class WhisperFeatureExtractor:
             raise ValueError(f"unsupported return_tensors={return_tensors!r}")
         elif return_tensors is None:
             feats = [f for f in feats.cpu().numpy()]
+        elif return_device != "cpu":
+            feats = feats.to(return_device)
         return BatchFeature({"input_features": feats})

@@ -61,6 +61,25 @@ def logmel(wave: torch.Tensor, n_samples: int | None = None) -> torch.Tensor:
     return out
 
 
+def logmel_host(wave, n_samples: int | None = None) -> torch.Tensor:
+    """CPU twin of :func:`logmel`: [n, L] fp32 host waveform -> [n, 80, 3000] fp32 CPU tensor.
+
+    Runs ``gww_logmel_host_f32`` (plain C++ inside libgww.so, no HIP call), so it works inside forked DataLoader
+    workers, where the reference calls the extractor (Signal_vs_Noise/src/dataset.py:20-21 under
+    src/train.py:224-225).  Not a fallback of the GPU path: callers pick it by handing over host data.
+    """
+    import numpy as np
+    w = np.ascontiguousarray(wave.numpy() if isinstance(wave, torch.Tensor) else wave, dtype=np.float32)
+    if w.ndim == 1:
+        w = w[None]
+    n, L = w.shape
+    n_samples = L if n_samples is None else n_samples
+    out = torch.empty((n, 80, 3000), dtype=torch.float32)
+    check(lib().gww_logmel_host_f32(w.ctypes.data, n, n_samples, max(L, 1) if n else 1, out.data_ptr()),
+          "gww_logmel_host_f32")
+    return out
+
+
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out_bf16: bool = False) -> torch.Tensor:
     x = _dev(x, torch.float32, "x")
     M, d = x.shape

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GWW_VERSION 102  /* 0.1.2: + whitening kernels, gww_qadapter_tail_f32, gww_attention_bwd_log2q_bf16, gww_lnqkv_fused_bf16, gww_attn_out_mlp_fused_bf16, gww_mlp_pack_op_bf16; the gww_mlp_pack_bf16 stream carries W1 / 8 and 8 W2 */
+#define GWW_VERSION 103  /* 0.1.3: + gww_logmel_host_f32 (fork-safe CPU twin of the front end); 0.1.2: + whitening kernels, gww_qadapter_tail_f32, gww_attention_bwd_log2q_bf16, gww_lnqkv_fused_bf16, gww_attn_out_mlp_fused_bf16, gww_mlp_pack_op_bf16; the gww_mlp_pack_bf16 stream carries W1 / 8 and 8 W2 */
 
 #define GWW_OK 0
 #define GWW_ERR_ARG (-1)      /* bad argument (shape, null pointer, unsupported size) */
@@ -60,6 +60,11 @@ int gww_frontend_create(gww_frontend** out);          /* uploads window / twiddl
 void gww_frontend_destroy(gww_frontend* fe);
 int gww_logmel_f32(gww_frontend* fe, const float* wave, int n_seg, int n_samples,
                    long wave_stride, float* out, float* seg_max, void* stream);
+/* The same front end on the HOST: wave and out are HOST pointers, nothing here touches the GPU (no HIP call, no
+ * handle, no global mutable state), so it may be called from forked DataLoader worker processes -- where the
+ * reference calls the extractor: Signal_vs_Noise/src/dataset.py:12,20-21 under src/train.py:224-225
+ * (num_workers 12).  Same arithmetic and the same dead-frame shortcut; double-precision FFT, fp32 result. */
+int gww_logmel_host_f32(const float* wave, int n_seg, int n_samples, long wave_stride, float* out);
 
 /* --------------------------------------------------------------------------
  * Encoder.  Replaces WhisperEncoder.forward as built at
