@@ -39,6 +39,12 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #ifndef GWW_MF_EXP
 #define GWW_MF_EXP 0   // diagnostic builds only: 1 = no DMA in the loop, 2 = no GELU, 4 = no fragment reads in the loop, 8 = stream folded onto its first 8 tiles, 16 = GELU bias not read from LDS, 32 = GELU transcendentals replaced by multiplies, 64 = no ring wait / barrier per tile
 #endif
+#ifndef GWW_MF_ABL
+#define GWW_MF_ABL 0   // diagnostic builds only (wrong results by design, only the time matters): 1 = q/k/v tail without its global
+                       // stores, 2 = without its n-tile epilogues, 4 = without DMA issue / ring waits, 8 = without barriers;
+                       // 16 = seams without their stores, 32 = without their loads; 64 = OP prologue without the ctx loads;
+                       // 128 = out_proj GEMM without DMA issue / ring waits
+#endif
 #ifndef GWW_MF_OLDDMA
 #define GWW_MF_OLDDMA 0   // diagnostic: round 1's eight-instruction DMA issue
 #endif
@@ -274,13 +280,15 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #pragma unroll
     for (int S = 0; S < MF_KT; ++S)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        if (GWW_MF_ABL & 64) { cv[S][i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; continue; }
         asm volatile("global_load_dwordx4 %0, %1, off offset:%2" MF_NT : "=v"(cv[S][i]) : "v"(crow_p[i]), "n"(64 * S * 2) : "memory");
+      }
 #pragma unroll
     for (int S = 0; S < MF_KT; ++S) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cv[S][i]) : "n"(23 - (4 * S + i)));
+        if (!(GWW_MF_ABL & 64)) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cv[S][i]) : "n"(23 - (4 * S + i)));
         *reinterpret_cast<u32x4*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + cchunk * 16) = cv[S][i];
       }
 #pragma unroll
@@ -736,6 +744,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
+                if (GWW_MF_ABL & 32) { xn4[q][h2][i] = f32x4{0.5f, -0.25f, 1.f, 0.f}; xa4[q][h2][i] = f32x4{0.5f, -0.25f, 1.f, 0.f}; continue; }
                 if (np == 0)
                   asm volatile("global_load_dwordx4 %0, %1, off offset:%2" MF_NT
                                : "=v"(xn4[q][h2][i]) : "v"(xrow2[i]), "n"((64 * (np + q) + 32 * h2) * 4) : "memory");
@@ -765,10 +774,10 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
             // whatever rows are masked)
             f32x4 v;
             if (np < 3) {
-              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xn4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
+              if (!(GWW_MF_ABL & 32)) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xn4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
               v = xn4[np % 3][h2][i];
             } else {
-              asm volatile("s_waitcnt vmcnt(%1)" : "+a"(xa4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
+              if (!(GWW_MF_ABL & 32)) asm volatile("s_waitcnt vmcnt(%1)" : "+a"(xa4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
               v = xa4[np % 3][h2][i];
             }
             const u32x2 dv = *reinterpret_cast<const u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8);
@@ -805,7 +814,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
               for (int i = 0; i < 4; ++i)
-                if (m_base + 8 * i + crow < M)
+                if (GWW_MF_ABL & 16) asm volatile("" :: "v"(xn4[q][h2][i]));
+                else if (m_base + 8 * i + crow < M)
                   *reinterpret_cast<f32x4*>(seam_dst + grow[i] * MF_D + 64 * (np - 2 + q) + 32 * h2 + 4 * cchunk) = xn4[q][h2][i];
           asm volatile("" ::: "memory");
         }
@@ -837,7 +847,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #pragma unroll
       for (int kt = 0; kt < MF_KT; ++kt) {
         const int itile = nt * MF_KT + kt;               // compile-time: the stage is static
-        mf_wait_vmcnt<MF_GL * (MF_AHEAD - 2)>();
+        if (!(GWW_MF_ABL & 128)) mf_wait_vmcnt<MF_GL * (MF_AHEAD - 2)>();
         __builtin_amdgcn_s_barrier();
         const int st = itile & 3, st_next = (itile + 1) & 3, dma_st = (itile + MF_AHEAD) & 3;
         const int dma_tile = itile + MF_AHEAD < total ? itile + MF_AHEAD : total - 1;
@@ -848,7 +858,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           bf16x8(&cur)[4] = wf[q & 1];
           bf16x8(&nxt)[4] = wf[(q + 1) & 1];
           const unsigned char* Wn = lds + (sub == 3 ? st_next : st) * MF_TILE;
-          issue_piece(dma_tile, dma_st, sub);
+          if (!(GWW_MF_ABL & 128)) issue_piece(dma_tile, dma_st, sub);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(oacc[4 * nt + u]) : "v"(cur[u]), "v"(af[4 * kt + sub]));
@@ -998,9 +1008,11 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         // the DMA group being waited for (tile it + 1) was issued during tile it + 1 - AHEAD; the 8 output stores of the
         // previous n-tile were issued in front of (nt, 0): they are YOUNGER than that group while kt <= AHEAD - 2 and may
         // then stay in flight
-        if (nt > 0 && kt <= MF_AHEAD - 2) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + 8>();
+        constexpr int TAIL_ST = (GWW_MF_ABL & 3) ? 0 : 8;   // output stores per n-tile in the vmcnt queue
+        if (GWW_MF_ABL & 4) {}
+        else if (nt > 0 && kt <= MF_AHEAD - 2) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + TAIL_ST>();
         else mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
-        __builtin_amdgcn_s_barrier();
+        if (!(GWW_MF_ABL & 8)) __builtin_amdgcn_s_barrier();
         TSTAMP(6);
         const int itq = T0 + nt * MF_KT + kt;
         const int dma_tile = itq + MF_AHEAD < total ? itq + MF_AHEAD : total - 1;
@@ -1013,7 +1025,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           bf16x8(&nxt)[4] = wf[(q + 1) & 1];
           const unsigned char* Wn = lds + (sub == 3 ? stage_next : stage) * MF_TILE + offq[(sub + 1) & 3];
           __builtin_amdgcn_sched_barrier(0);
-          issue_piece(dma_tile, dma_stage, sub);
+          if (!(GWW_MF_ABL & 4)) issue_piece(dma_tile, dma_stage, sub);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
 #if GWW_MF_SCHED
@@ -1058,6 +1070,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #endif
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
+        if (GWW_MF_ABL & 2) break;
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int t = 2 * half + tt;
@@ -1087,6 +1100,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         for (int i = 0; i < 4; ++i) {
           const u32x4 u = *reinterpret_cast<const u32x4*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + cchunk * 16);
           const long orow = m_base + 8 * i + crow;
+          if (GWW_MF_ABL & 1) { asm volatile("" :: "v"(u)); continue; }
 #if GWW_MF_NTSTORE
           __builtin_nontemporal_store(u, reinterpret_cast<u32x4*>(q_out + orow * NQ + nt * 128 + 64 * half + 8 * cchunk));
 #else
@@ -1097,7 +1111,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     }
     // the ring's re-reads issued past the end must have landed before this workgroup's LDS is handed on; they are older
     // than the last n-tile's 8 output stores, which need not be waited for (vmcnt counts in issue order)
-    mf_wait_vmcnt<8>();
+    mf_wait_vmcnt<(GWW_MF_ABL & 3) ? 0 : 8>();
   }
   MSTAMP(3);
   MSTAMP_FLUSH

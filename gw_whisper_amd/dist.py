@@ -23,12 +23,14 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend: str | None = None) -> Tuple[int, int, int]:
-    """Initialise from the torchrun environment; returns (rank, world, local_rank)."""
+def init(backend: str | None = None, force: bool = False) -> Tuple[int, int, int]:
+    """Initialise from the torchrun environment; returns (rank, world, local_rank).  A single process needs no group
+    and gets none unless ``force`` asks for one (a world-size-1 RCCL group still runs every collective through the
+    library: the hardware check of this path on a one-GPU box, tests/test_gpu_dist.py)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -39,6 +41,10 @@ def init(backend: str | None = None) -> Tuple[int, int, int]:
         else:
             dist.init_process_group(backend)
     return rank, world, local
+
+
+def _group_up() -> bool:
+    return dist.is_available() and dist.is_initialized()
 
 
 def shard_range(n_items: int, rank: int, world: int, batch: int = 1) -> Tuple[int, int]:
@@ -72,7 +78,7 @@ def step_active(n_items: int, step: int, world: int, batch: int) -> int:
 
 def broadcast_scalar(value: float, world: int, device=None, src: int = 0) -> float:
     """Rank ``src``'s value on every rank: early stopping / best-checkpoint decisions must not diverge."""
-    if world == 1:
+    if world == 1 and not _group_up():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.broadcast(t, src=src)
@@ -81,7 +87,7 @@ def broadcast_scalar(value: float, world: int, device=None, src: int = 0) -> flo
 
 def gather_concat(local: torch.Tensor, n_items: int, rank: int, world: int, batch: int = 1) -> torch.Tensor | None:
     """Gather the per-rank result rows (in ``shard_range`` order) on rank 0."""
-    if world == 1:
+    if world == 1 and not _group_up():
         return local
     sizes = [shard_range(n_items, r, world, batch) for r in range(world)]
     pad = max(b - a for a, b in sizes)
@@ -95,8 +101,8 @@ def gather_concat(local: torch.Tensor, n_items: int, rank: int, world: int, batc
 
 
 class FlatGradBucket:
-    """One flat fp32 buffer over the trainable parameters' gradients: a single
-    ``all_reduce(SUM)`` per step, then an in-place divide by the world size."""
+    """One flat fp32 buffer over the trainable parameters' gradients (+ one trailing word for the sample count): a
+    single ``all_reduce(SUM)`` per step, then an in-place divide."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -104,17 +110,34 @@ class FlatGradBucket:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
         self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self._buf = torch.zeros(self.numel + 1, dtype=torch.float32, device=dev)   # [gradients | sample count]
+        self.flat = self._buf[: self.numel]
         off = 0
         for p in self.params:          # gradients become views into the flat buffer
             p.grad = self.flat[off: off + p.numel()].view_as(p)
             off += p.numel()
 
     def zero(self):
-        self.flat.zero_()
+        self._buf.zero_()
 
-    def all_reduce_mean(self, world: int, active: int | None = None):
-        """Sum over ranks, divide by ``active`` (default ``world``): ranks without a batch in this step hold zeros."""
-        if world > 1:
+    def all_reduce_mean(self, world: int, active: int | None = None, n_local: int | None = None):
+        """Sum over ranks and divide.
+
+        ``n_local`` (the samples behind this rank's batch-MEAN gradient, 0 for a rank without a batch) gives the
+        sample-weighted mean ``sum_r n_r g_r / sum_r n_r`` -- the gradient of the mean loss over the whole global batch,
+        so a 3-sample tail batch on one rank weighs 3 samples, not as much as a full batch elsewhere, and the update does
+        not depend on how the batch was cut over ranks.  The count travels in the bucket's trailing word: still ONE
+        collective.  Without it: the plain mean over ``active`` (default ``world``) ranks.
+        """
+        grouped = _group_up()
+        if n_local is not None:
+            self.flat.mul_(float(n_local))
+            self._buf[self.numel] = float(n_local)
+            if grouped:
+                dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)
+            self.flat.div_(self._buf[self.numel].clamp_min(1.0))
+            return
+        if grouped:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if world > 1:
             self.flat.div_(world if active is None else max(int(active), 1))

@@ -103,6 +103,10 @@ class WhisperEncoder(nn.Module):
             self.embed_positions.weight.copy_(torch.from_numpy(synth.sinusoid_table(config.max_source_positions, d)))
         self.layers = nn.ModuleList([_EncoderLayer(d, config.encoder_ffn_dim) for _ in range(config.encoder_layers)])
         self.layer_norm = nn.LayerNorm(d)
+        # The base is born frozen: no base-weight backward exists here, so a freshly built
+        # encoder runs inference with or without torch.no_grad(); only an explicit un-freeze (the reference's
+        # full_finetune, Signal_vs_Noise/src/train.py:244-250) meets the refusal in _wants_grad.
+        self._freeze_parameters()
         self.precision = precision
         self.gradient_checkpointing = False
         self._handle = None
@@ -274,9 +278,11 @@ class WhisperEncoder(nn.Module):
     def _wants_grad(self, input_features) -> bool:
         if not torch.is_grad_enabled():
             return False
-        # Only the frozen-base + DoRA backward exists (and the input gradient).  A trainable base parameter -- the
-        # reference's `full_finetune` method, Signal_vs_Noise/src/train.py:244-250, or an encoder used without peft
-        # whose parameters were never frozen -- or a plain-LoRA adapter would silently get no gradient: refuse.
+        # Only the frozen-base + DoRA backward exists (and the input gradient).  A base parameter that was un-frozen on
+        # purpose -- the reference's `full_finetune` method, Signal_vs_Noise/src/train.py:244-250 -- would silently get no
+        # gradient: refuse.  (Cheap path first: nothing trainable at all is the inference case.)
+        if not any(p.requires_grad for p in self.parameters()):
+            return torch.is_tensor(input_features) and input_features.requires_grad
         base_trainable = [n for n, p in self.named_parameters() if p.requires_grad and "lora_" not in n]
         if base_trainable:
             raise _lib.GwwError(

@@ -117,8 +117,13 @@ def main(args):
         # resume (src/train.py:44-60): the saved adapter is loaded onto the BARE encoder -- PeftModel.from_pretrained
         # wraps the nn.Linear targets itself -- and stays trainable
         from gw_whisper_amd.peft import PeftModel
-        peft = PeftModel.from_pretrained(encoder, os.path.join(args.load_model_path, args.load_lora_weights),
-                                         is_trainable=True).to(device)
+        adapter_dir = _resume_path(args.load_model_path, args.load_lora_weights)
+        with open(os.path.join(adapter_dir, "adapter_config.json")) as f:
+            saved_dora = bool(json.load(f).get("use_dora", False))
+        if saved_dora != (args.method == "DoRA"):
+            raise ValueError(f"--method {args.method} but the adapter in {adapter_dir} was saved with use_dora={saved_dora}: "
+                             "resume with the method it was trained with")
+        peft = PeftModel.from_pretrained(encoder, adapter_dir, is_trainable=True).to(device)
     else:
         peft = get_peft_model(encoder, LoraConfig(use_dora=args.method == "DoRA", r=args.lora_rank,   # src/train.py:253, :263
                                                   lora_alpha=args.lora_alpha, target_modules=matched)).to(device)
@@ -126,7 +131,7 @@ def main(args):
         p.requires_grad = "lora" in name
     model = two_channel_ligo_binary_classifier(peft).to(device)
     if args.load_model_path:
-        model.classifier.load_state_dict(torch.load(os.path.join(args.load_model_path, args.load_dense_weights),
+        model.classifier.load_state_dict(torch.load(_resume_path(args.load_model_path, args.load_dense_weights),
                                                     map_location=device))
     params = [p for p in model.parameters() if p.requires_grad]
     optimizer = torch.optim.AdamW(params, lr=args.learning_rate, betas=(0.9, 0.999), eps=1e-08)
@@ -172,8 +177,9 @@ def main(args):
         model.train()
         order = np.random.default_rng(args.seed + 1 + epoch).permutation(train_idx)
         t0, run, nb, seen = time.time(), 0.0, 0, 0
-        # every rank runs the SAME number of steps (one all-reduce each); a rank without a batch in the last step
-        # contributes zeros and the mean is taken over the active ranks
+        # every rank runs the SAME number of steps (one all-reduce each); the bucket takes the SAMPLE-weighted mean over
+        # the ranks (a rank without a batch in the last step contributes zero samples), i.e. the gradient of the mean loss
+        # over the whole global batch whatever the number of ranks
         for step in range(gdist.epoch_steps(len(order), world, args.batch_size)):
             sl = gdist.step_slice(len(order), step, rank, world, args.batch_size)
             bucket.zero()
@@ -186,7 +192,7 @@ def main(args):
                 run += loss.item()
                 nb += 1
                 seen += len(idx)
-            bucket.all_reduce_mean(world, active=gdist.step_active(len(order), step, world, args.batch_size))
+            bucket.all_reduce_mean(world, n_local=0 if sl is None else sl[1] - sl[0])
             optimizer.step()
         train_loss = run / max(nb, 1)
         val_loss, val_auc = evaluate()
@@ -209,6 +215,16 @@ def main(args):
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def _resume_path(base: str, name: str) -> str:
+    """The reference builds resume paths by plain string concatenation, ``load_model_path + load_lora_weights``
+    (Signal_vs_Noise/src/train.py:292): that form first, ``os.path.join`` (a base directory without the trailing
+    separator) second; whichever exists."""
+    for cand in (base + name, os.path.join(base, name)):
+        if os.path.exists(cand):
+            return cand
+    raise FileNotFoundError(f"neither {base + name!r} nor {os.path.join(base, name)!r} exists")
 
 
 if __name__ == "__main__":

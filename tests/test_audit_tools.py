@@ -39,9 +39,28 @@ def test_asm_mfma_audit_flags_an_early_read_of_the_result(tmp_path):
     assert rc == 1 and "reads the result of asm MFMA" in out
     rc, out = _run("audit_asm_mfma.py", mf + "\ts_nop 10\n\tv_mul_f32_e32 v136, v48, v48\n", tmp_path)
     assert rc == 0
-    # an MFMA in between occupies the pipe for its 8 passes
-    rc, out = _run("audit_asm_mfma.py", mf + _asm("v_mfma_f32_32x32x16_bf16 v[16:31], v[168:171], v[64:67], v[16:31]")
-                   + "\ts_nop 2\n\tv_mul_f32_e32 v136, v48, v48\n", tmp_path)
+    # an MFMA in between issues 8 wait states after the first (the pipe is busy) and the reader 3 + 1 behind it
+    other = _asm("v_mfma_f32_32x32x16_bf16 v[16:31], v[168:171], v[64:67], v[16:31]")
+    rc, out = _run("audit_asm_mfma.py", mf + other + "\ts_nop 2\n\tv_mul_f32_e32 v136, v48, v48\n", tmp_path)
+    assert rc == 0
+    # ... but it only WAITS for the pipe, it does not add 8 on top of what already went by: A, 3 VALU, B, reader has
+    # about 8 wait states, not 3 + 8 (round 2's model passed this listing)
+    valu3 = "\tv_add_f32_e32 v1, v2, v3\n" * 3
+    rc, out = _run("audit_asm_mfma.py", mf + valu3 + other + "\tv_mul_f32_e32 v136, v48, v48\n", tmp_path)
+    assert rc == 1 and "after 8 wait state" in out
+
+
+def test_asm_mfma_audit_sees_stores_and_mfma_operands_reading_a_result(tmp_path):
+    mf = _asm("v_mfma_f32_32x32x16_bf16 v[48:63], v[168:171], v[64:67], v[48:63]")
+    for reader in ("ds_write_b64 v200, v[48:49] offset:16", "global_store_dwordx4 v[2:3], v[52:55], off",
+                   "buffer_store_dwordx2 v[60:61], v7, s[0:3], 0 offen",
+                   "v_mfma_f32_32x32x16_bf16 a[0:15], v[48:51], v[64:67], a[0:15]"):
+        rc, out = _run("audit_asm_mfma.py", mf + "\ts_nop 3\n\t" + reader + "\n", tmp_path)
+        assert rc == 1 and "reads the result of asm MFMA" in out, reader
+        rc, out = _run("audit_asm_mfma.py", mf + "\ts_nop 10\n\t" + reader + "\n", tmp_path)
+        assert rc == 0, reader
+    # the accumulate chain itself (same registers as SrcC and destination) is not a hazard
+    rc, out = _run("audit_asm_mfma.py", mf + mf, tmp_path)
     assert rc == 0
 
 

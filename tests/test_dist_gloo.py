@@ -137,3 +137,62 @@ def test_two_rank_epoch_loop_with_a_ragged_number_of_batches(tmp_path):
             opt.step()
     torch.testing.assert_close(e0["w"], model.weight.detach())
     torch.testing.assert_close(e0["b"], model.bias.detach())
+
+
+def _weighted_worker(rank, world, port, tmp):
+    """Sample-weighted bucket mean: 77 items at batch 16 on 2 ranks -- the last global step holds ONE batch of 13 items,
+    the one before it two full batches; every step must equal the single-process gradient of the mean loss over the
+    step's items, whatever the cut over ranks."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    gdist.init("gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Linear(6, 1)
+    bucket = gdist.FlatGradBucket(model.parameters())
+    g = torch.Generator().manual_seed(1)
+    X, y = torch.randn(77, 6, generator=g), torch.randn(77, 1, generator=g)
+    grads = []
+    for n_items in (77, 35):          # 35: step 1 = one batch of 3 items on rank 0 next to nothing on rank 1
+        for step in range(gdist.epoch_steps(n_items, world, 16)):
+            sl = gdist.step_slice(n_items, step, rank, world, 16)
+            bucket.zero()
+            if sl is not None:
+                torch.nn.functional.mse_loss(model(X[sl[0]:sl[1]]), y[sl[0]:sl[1]]).backward()
+            bucket.all_reduce_mean(world, n_local=0 if sl is None else sl[1] - sl[0])
+            grads.append(bucket.flat.clone())
+    torch.save(grads, os.path.join(tmp, f"w{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_sample_weighted_mean_equals_the_single_process_gradient(tmp_path):
+    port = _free_port()
+    mp.spawn(_weighted_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    w0, w1 = torch.load(tmp_path / "w0.pt"), torch.load(tmp_path / "w1.pt")
+    torch.manual_seed(0)
+    model = torch.nn.Linear(6, 1)
+    g = torch.Generator().manual_seed(1)
+    X, y = torch.randn(77, 6, generator=g), torch.randn(77, 1, generator=g)
+    k = 0
+    for n_items in (77, 35):
+        for step in range(gdist.epoch_steps(n_items, 2, 16)):
+            lo, hi = step * 32, min(n_items, step * 32 + 32)      # the global batch of this step, as ONE batch
+            model.zero_grad()
+            torch.nn.functional.mse_loss(model(X[lo:hi]), y[lo:hi]).backward()
+            ref = torch.cat([model.weight.grad.flatten(), model.bias.grad.flatten()])
+            torch.testing.assert_close(w0[k], ref)
+            assert torch.equal(w0[k], w1[k])
+            k += 1
+    assert k == len(w0) == 5
+
+
+def test_single_process_bucket_needs_no_group():
+    model = torch.nn.Linear(3, 2)
+    bucket = gdist.FlatGradBucket(model.parameters())
+    model(torch.ones(4, 3)).sum().backward()
+    ref = bucket.flat.clone()
+    bucket.all_reduce_mean(1)
+    assert torch.equal(bucket.flat, ref)
+    bucket.all_reduce_mean(1, n_local=4)
+    torch.testing.assert_close(bucket.flat, ref)

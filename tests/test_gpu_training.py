@@ -593,14 +593,19 @@ def test_save_then_resume_gives_the_same_model_and_keeps_training(T, gww, tmp_pa
 
 
 def test_encoder_refuses_to_silently_drop_base_gradients(T, gww):
-    """A WhisperEncoder whose base parameters still require grad (the reference's full_finetune method, or no peft at
-    all) must not return a detached output under autograd: only the frozen-base + DoRA step exists."""
+    """A WhisperEncoder whose base parameters were un-frozen (the reference's full_finetune method) must not return a
+    detached output under autograd: only the frozen-base + DoRA step exists.  A freshly built encoder is frozen and
+    simply runs inference, with or without torch.no_grad()."""
     import gw_whisper_amd as g
     from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
     sd = synth.encoder_state_dict(128, 2, 2, 512, seed=3)
     enc = WhisperEncoder.from_numpy_state_dict(sd, WhisperConfig(128, 2, 2, 512), precision="bf16").cuda()
     mel = T.from_numpy(olm.log_mel(synth.strain_segments(1, seed=1))).cuda()
+    assert not any(p.requires_grad for p in enc.parameters())
+    plain = enc(mel).last_hidden_state                       # autograd on, nothing trainable: inference
+    assert not plain.requires_grad and T.isfinite(plain).all()
+    enc.layers[0].fc1.weight.requires_grad_(True)            # what full_finetune does
     with pytest.raises(g.GwwError, match="frozen-base"):
         enc(mel)
     with T.no_grad():
-        assert T.isfinite(enc(mel).last_hidden_state).all()
+        assert T.equal(enc(mel).last_hidden_state, plain)
