@@ -114,6 +114,11 @@ SIGNATURES = {
                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gww_qadapter_tail_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "gww_qadapter_cnn_packed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "gww_qadapter_cnn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gww_qadapter_cnn_pack_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "gww_qadapter_cnn_forward_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "gww_welch_power_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "gww_column_median_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
     "gww_fir_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p]),
@@ -124,7 +129,7 @@ SIGNATURES = {
     "gww_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
 }
 
-ABI_VERSION = 103   # include/gww.h GWW_VERSION this binding was written against
+ABI_VERSION = 104   # include/gww.h GWW_VERSION this binding was written against
 
 _lib = None
 

@@ -30,6 +30,12 @@ int fail(int code, const char* fmt, ...);
     if (!(cond)) return ::gww::fail(GWW_ERR_ARG, __VA_ARGS__); \
   } while (0)
 
+#define GWW_TRY(expr)          \
+  do {                         \
+    int _rc = (expr);          \
+    if (_rc != GWW_OK) return _rc; \
+  } while (0)
+
 // ---- vector types ---------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

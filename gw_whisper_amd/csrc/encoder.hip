@@ -261,12 +261,6 @@ extern "C" void gww_encoder_destroy(gww_encoder* e) {
   delete e;
 }
 
-#define GWW_TRY(expr)          \
-  do {                         \
-    int _rc = (expr);          \
-    if (_rc != GWW_OK) return _rc; \
-  } while (0)
-
 // Weight groups of one layer (bit mask of gww_encoder_update_weights): what has to be re-packed when a
 // parameter of the group changed.
 //   1 = q / k / v projections + their biases + self_attn_layer_norm   (QKV panels, LN-folded panel, transposes)
@@ -357,7 +351,11 @@ static int pack_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_
       if (!(m & 14u) && !(mn & 1u)) continue;   // (bit 1: out_proj, in front of the wmlp_op stream)
       LayerW& w = e->layers[i];
       const void* wq_next = i + 1 < n_layers ? e->layers[i + 1].wqkv_ln : nullptr;
-      if ((m & 12u) || (mn & 1u)) GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, wq_next, w.wmlp, d, F, 3 * d, s));
+      // Only the stream the active path consumes is packed: the inference and the training forward both run the block with
+      // out_proj in front (wmlp_op); the stream without it serves the debug paths GWW_GENERIC_PATH bits 4 / 7 alone (a
+      // DoRA step used to pay two full fc1 + fc2 + q/k/v stream packs per layer, 2 x 3.2 MB of writes, for one consumer).
+      static const bool plain_stream = getenv("GWW_GENERIC_PATH") && (atoi(getenv("GWW_GENERIC_PATH")) & (16 | 128));
+      if (plain_stream && ((m & 12u) || (mn & 1u))) GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, wq_next, w.wmlp, d, F, 3 * d, s));
       GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, wq_next, w.wmlp_op, d, F, 3 * d, s, w.wo));
     }
     if (!dirty || (dirty[0] & 1u))   // layer 0's folded q / k / v panel alone (no MLP in front of it)
@@ -582,9 +580,9 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
       if (mlp_fused && fuse_qkv && i + 1 < e->cfg.n_layers) {
         // ... and the next layer's LN1 + q / k / v projection appended: xn receives x_next (no delta pending)
         const LayerW& Ln = e->layers[i + 1];
+        // (x_next comes back in xc itself: xn only holds x_new, the block's intermediate residual stream)
         TR(TR_MLPQKV, launch_mlp_fused(xc, op ? ctx : d1, xn, L.u1, L.cb1, op ? L.wmlp_op : L.wmlp, L.b2, nullptr, M, d, F, s,
                                        Ln.uqkv, Ln.cbqkv, qkv, 3 * d, nullptr, op ? L.bo : nullptr));
-        { float* t = xc; xc = xn; xn = t; }
         pending = nullptr;
         qkv_done = true;
         continue;

@@ -92,7 +92,8 @@ constexpr int MF_OFF_CB = MF_NST_MAX * MF_TILE;
 constexpr int MF_OFF_U = MF_OFF_CB + MF_FMAX * 4;
 constexpr int MF_OFF_B2 = MF_OFF_U + MF_FMAX * 4;
 constexpr int MF_OFF_BO = MF_OFF_B2 + MF_D * 4;     // out_proj bias (OP mode)
-constexpr int MF_OFF_SLICE = MF_OFF_BO + MF_D * 4;
+constexpr int MF_OFF_QCB = MF_OFF_BO + MF_D * 4;    // folded bias of the appended q / k / v panel (staged at kernel start)
+constexpr int MF_OFF_SLICE = MF_OFF_QCB + MF_FMAX * 4;
 constexpr int MF_LDS = MF_OFF_SLICE + MF_WAVES * MF_SLICE_BYTES;
 static_assert(MF_LDS <= 160 * 1024, "LDS budget");
 
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   float* lds_u = reinterpret_cast<float*>(lds + MF_OFF_U);
   float* lds_b2 = reinterpret_cast<float*>(lds + MF_OFF_B2);
   float* lds_bo = reinterpret_cast<float*>(lds + MF_OFF_BO);
+  float* lds_qcb = reinterpret_cast<float*>(lds + MF_OFF_QCB);
   constexpr int OP_TILES = OP ? 3 * MF_KT : 0;   // W_o tiles in front of the stream
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -243,6 +245,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     for (int i = tid; i < MF_D; i += MF_THREADS) lds_b2[i] = b2[i];
   if (OP)
     for (int i = tid; i < MF_D; i += MF_THREADS) lds_bo[i] = bo[i];
+  if (QKV && GWW_MF_NORM)   // (a load issued behind the second seam's stores would wait for them: staged here, 6 KB of LDS)
+    for (int i = tid; i < NQ; i += MF_THREADS) lds_qcb[i] = q_cb[i];
   // De-phase the first round of workgroups (later ones inherit the offsets as CUs free up): panels take
   // the same time everywhere, so without this every CU is in its HBM phase (prologue / epilogue) at the
   // same moment and idles HBM during the MFMA phase.
@@ -592,6 +596,11 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     // copies (v_accvgpr_mov / _write into an accumulator tile it re-homes between the loop and the epilogue) directly in
     // front of an MFMA it cannot recognise inside an asm statement; the build's ISA audit checks that none is left.
     constexpr bool PAD = decltype(pad_c)::value != 0;
+    // pad_c == 2: no ring wait in front of this tile.  Behind a seam the wave has consumed loads that were issued AFTER the
+    // DMA pieces of the next two tiles: operations retire in issue order, so those pieces have landed -- while a counted
+    // wait here would also wait for the seam's last stores, which are younger than the pieces and have no business
+    // holding up a tile that does not need them (they get two tile times until the first tile whose pieces are younger).
+    constexpr bool NOWAIT = decltype(pad_c)::value == 2;
     constexpr int PRE = decltype(pre_c)::value;   // >= 0: parity of the accumulator pair whose bias is preloaded in this tile
     // A four-stage ring makes the stage of every tile of the unrolled 12-tile body a compile-time constant (flat tile
     // index mod 4): every fragment address is then base register + immediate (no v_or_b32 per read: 8 cycles each
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     constexpr int ST = MF_NST == 4 ? ((decltype(flat_c)::value + OP_TILES) & 3) : -1;
     if (ST >= 0) stage = ST;
     if constexpr (!(GWW_MF_EXP & 64)) {   // (64: diagnostic, no ring wait / barrier -- only meaningful together with 1)
-      mf_wait_vmcnt<MF_GL * (MF_AHEAD - 2)>();
+      if (!NOWAIT) mf_wait_vmcnt<MF_GL * (MF_AHEAD - 2)>();
       __builtin_amdgcn_s_barrier();
     }
     MSTAMP(1);
@@ -722,7 +731,19 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   // measured / packed into the A fragments of k-tile np.  Used behind fc2 (src = x_new, dst = x_next, bias = b2: the
   // operand of the next layer's q / k / v) and -- OP mode -- behind the fused out_proj (src = x, dst = x_new, bias = bo:
   // the operand of fc1).  The ring tiles in flight are older than these loads: hipcc's own vmcnt waits retire them first.
-  auto seam = [&](const float* seam_src, float* seam_dst, const float* seam_bias) {
+  // Stores go out chunk by chunk (8 per 64-column chunk) and the second batch of loads is requested BEFORE the stores of
+  // the chunk just finished: loads, stores and LDS-DMA retire in issue order, so a wait for a load that sits behind 24
+  // fresh stores also waits for those stores to reach the L2 (round 2 order: 24 stores, then 24 loads, then the waits --
+  // store drain + load latency in series, twice per seam; GWW_MF_ABL = 16 / 32 / 48 builds).  Now the waits name the
+  // stores issued since the request as younger operations and leave them in flight.  That needs EXACT queue counts: loads
+  // and stores are asm, every lane of every store is live.  Rows past M are clamped duplicates of row M - 1 on both
+  // sides: every duplicate computes and stores the same value, which is harmless as long as the seam does not run in
+  // place (seam_dst != seam_src: the launcher guarantees it, x_next goes to the buffer x came from).  Addresses are one
+  // 32-bit row offset per lane and row + a scalar base (M * 1536 bytes < 4 GiB is checked at launch).
+  auto seam = [&](const float* seam_src, float* seam_dst, const float* seam_bias, auto&& after_request) {
+      unsigned roff[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) roff[i] = (unsigned)grow[i] * (unsigned)(MF_D * 4) + 16u * (unsigned)cchunk;
 
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, cshift[4];
       // the x_new lines of three 64-column chunks are requested together (24 loads per lane; with the 192 output
@@ -732,26 +753,38 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       //  hipcc would otherwise copy the just-requested registers away BEFORE the data has landed; half of the output
       //  accumulators are free at that point)
       f32x4 xn4[3][2][4], xa4[3][2][4];
-      const float* xrow2[4];
+      auto request = [&](int np0) {   // the 24 loads of chunks np0 .. np0 + 2
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xrow2[i] = seam_src + grow[i] * MF_D + 4 * cchunk;
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (GWW_MF_ABL & 32) { xn4[q][h2][i] = f32x4{0.5f, -0.25f, 1.f, 0.f}; xa4[q][h2][i] = f32x4{0.5f, -0.25f, 1.f, 0.f}; continue; }
+              if (np0 == 0)
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" MF_NT
+                             : "=v"(xn4[q][h2][i]) : "v"(roff[i]), "s"(seam_src), "n"((64 * q + 32 * h2) * 4) : "memory");
+              else
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" MF_NT
+                             : "=a"(xa4[q][h2][i]) : "v"(roff[i]), "s"(seam_src), "n"((64 * (3 + q) + 32 * h2) * 4) : "memory");
+            }
+      };
+      auto store_chunk = [&](int np) {   // x_next of chunk np: 8 stores, every lane live (the s_nop covers the interval in
+                                         // which the store still reads its data registers)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (GWW_MF_ABL & 16) asm volatile("" :: "v"(xn4[np % 3][h2][i]));
+            else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1"
+                              : : "v"(roff[i]), "v"(xn4[np % 3][h2][i]), "s"(seam_dst), "n"((64 * np + 32 * h2) * 4) : "memory");
+          }
+      };
 #pragma unroll
       for (int np = 0; np < MF_KT; ++np) {
-        if (np % 3 == 0) {
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                if (GWW_MF_ABL & 32) { xn4[q][h2][i] = f32x4{0.5f, -0.25f, 1.f, 0.f}; xa4[q][h2][i] = f32x4{0.5f, -0.25f, 1.f, 0.f}; continue; }
-                if (np == 0)
-                  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" MF_NT
-                               : "=v"(xn4[q][h2][i]) : "v"(xrow2[i]), "n"((64 * (np + q) + 32 * h2) * 4) : "memory");
-                else
-                  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" MF_NT
-                               : "=a"(xa4[q][h2][i]) : "v"(xrow2[i]), "n"((64 * (np + q) + 32 * h2) * 4) : "memory");
-              }
+        if (np == 0) {
+          request(0);
+          after_request();   // work whose own memory latency runs beside the first batch's
         }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -769,15 +802,15 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            // load k = 8 (np % 3) + 4 h2 + i of the batch: at most the 23 - k younger loads may be outstanding
-            // (the x_next stores are issued only after the whole batch is consumed: the count stays exact
-            // whatever rows are masked)
+            // load k = 8 (np % 3) + 4 h2 + i of its batch: the 23 - k younger loads of the batch and the 8 stores of every
+            // chunk finished since the request (the second batch is requested in front of chunk 2's stores) may be outstanding
+            const int ST_SINCE = 8 * (np % 3) + (np >= 3 ? 8 : 0);
             f32x4 v;
             if (np < 3) {
-              if (!(GWW_MF_ABL & 32)) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xn4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
+              if (!(GWW_MF_ABL & 32)) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xn4[np % 3][h2][i]) : "n"(ST_SINCE + 23 - (8 * (np % 3) + 4 * h2 + i)));
               v = xn4[np % 3][h2][i];
             } else {
-              if (!(GWW_MF_ABL & 32)) asm volatile("s_waitcnt vmcnt(%1)" : "+a"(xa4[np % 3][h2][i]) : "n"(23 - (8 * (np % 3) + 4 * h2 + i)));
+              if (!(GWW_MF_ABL & 32)) asm volatile("s_waitcnt vmcnt(%1)" : "+a"(xa4[np % 3][h2][i]) : "n"(ST_SINCE + 23 - (8 * (np % 3) + 4 * h2 + i)));
               v = xa4[np % 3][h2][i];
             }
             const u32x2 dv = *reinterpret_cast<const u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8);
@@ -785,7 +818,6 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
             v[1] += bf2f((unsigned short)(dv[0] >> 16));
             v[2] += bf2f((unsigned short)(dv[1] & 0xffff));
             v[3] += bf2f((unsigned short)(dv[1] >> 16));
-            // rows past M are clamped duplicates of row M - 1: only the real row may update in place
             xn4[np % 3][h2][i] = v;      // x_next, stored once the batch is consumed
             if (np == 0 && h2 == 0) {
               float t = (v[0] + v[1]) + (v[2] + v[3]);
@@ -806,19 +838,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           asm volatile("" : "+v"(u)::"memory");
           af[4 * np + j] = __builtin_bit_cast(bf16x8, u);
         }
-        if (np % 3 == 2) {   // batch consumed: x_next of its three chunks back in place (real rows only: rows past M
-                             // are clamped duplicates of row M - 1 and must not touch it)
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-                if (GWW_MF_ABL & 16) asm volatile("" :: "v"(xn4[q][h2][i]));
-                else if (m_base + 8 * i + crow < M)
-                  *reinterpret_cast<f32x4*>(seam_dst + grow[i] * MF_D + 64 * (np - 2 + q) + 32 * h2 + 4 * cchunk) = xn4[q][h2][i];
-          asm volatile("" ::: "memory");
-        }
+        if (np == 2) request(3);   // batch 0 consumed: batch 1 is requested first, chunk 2's stores go behind it
+        store_chunk(np);
       }
       float* stat = reinterpret_cast<float*>(slice);
 #pragma unroll
@@ -874,7 +895,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     asm volatile("s_nop 15\n\ts_nop 15"
                  : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]), "+a"(oacc[3]), "+a"(oacc[4]), "+a"(oacc[5]), "+a"(oacc[6]),
                    "+a"(oacc[7]), "+a"(oacc[8]), "+a"(oacc[9]), "+a"(oacc[10]), "+a"(oacc[11]));
-    seam(X, x_out, lds_bo);     // x_new = x + bf16(ctx W_o^T + bo): written to x_out, LN2 statistics, A fragments
+    // x_new = x + bf16(ctx W_o^T + bo): written to x_out, LN2 statistics, A fragments
+    seam(X, x_out, lds_bo, [] {});
 #if GWW_MF_NORM
     normalise_af();
 #endif
@@ -892,8 +914,9 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       for (int q = 0; q < 4; ++q) preload_bias(t, t >> 1, q);
   }
   // G1(0): no GELU to carry yet; its first half is then computed in the open (once per 128 rows)
-  run_tile(MF_FL<0>{}, I0{}, I0{}, I0{}, IM{}, 0, 0, IM{}, 0, I1{});
-  run_tile(MF_FL<1>{}, I0{}, I0{}, I1{}, IM{}, 0, 0, IM{}, 0, I1{});
+  using IW = std::conditional_t<OP && !(GWW_MF_ABL & 32), I2, I1>;   // behind the out_proj seam: tiles 0 / 1 have landed
+  run_tile(MF_FL<0>{}, I0{}, I0{}, I0{}, IM{}, 0, 0, IM{}, 0, IW{});
+  run_tile(MF_FL<1>{}, I0{}, I0{}, I1{}, IM{}, 0, 0, IM{}, 0, IW{});
   run_tile(MF_FL<2>{}, I0{}, I0{}, I2{}, IM{}, 0, 0, IM{}, 0, I1{});
   // (hipcc cannot see that the asm MFMAs write S: the MFMA-write -> VALU-read interval is padded by hand)
   TSTAMP(12);
@@ -971,19 +994,20 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     // path, which keeps x_new as x_mid), and shifted / measured / packed into the A fragments of k-tile np.
     // The tiles already in flight are older than these loads: hipcc's own vmcnt waits retire them first.
     if constexpr (!LNQ) {   // the seam (MODE 2: the prologue already produced the normalised operand of LN1)
-      seam(x_out, x_next, lds_b2);
+      seam(x_out, x_next, lds_b2, [] {});
 #if GWW_MF_NORM
     normalise_af();
+#else
+      // (round 1's per-value LayerNorm algebra reads u and cb of the panel from the fc1 tables' place)
+      for (int i = tid; i < NQ; i += MF_THREADS) { lds_qcb[i] = q_cb[i]; lds_u[i] = q_u[i]; }
+      mf_wait_vmcnt<0>();
 #endif
+    } else {
+      mf_wait_vmcnt<0>();             // MODE 2: every tile issued so far has landed (this wave's pieces)
     }
-    // u / cb of the QKV panel replace fc1's (every wave is past its last GELU piece: those end three tiles, i.e.
-    // three barriers, before the loop exit)
-    for (int i = tid; i < NQ; i += MF_THREADS) {
-      lds_cb[i] = q_cb[i];
-      lds_u[i] = q_u[i];
-    }
-    mf_wait_vmcnt<0>();               // x_next stores retired, every tile issued so far has landed (this wave's pieces)
-    __builtin_amdgcn_s_barrier();     // ... and everybody else's; u / cb visible
+    // Behind the seam no counted wait is needed: its loads were issued after the DMA pieces of the first two tail tiles and
+    // have been consumed, so those pieces have landed (issue-order retirement), and its last x_next stores stay in flight.
+    __builtin_amdgcn_s_barrier();     // everybody's pieces visible
 
     MSTAMP(5);
     // ---- second GEMM: qkv[32 rows, NQ] = LN1(x_next) Wqkv'^T, n-tiles of 128 columns, 6 k-tiles each
@@ -999,7 +1023,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-          const float4 bv = *reinterpret_cast<const float4*>(lds_cb + 128 * nt + 32 * t + 8 * cc + 4 * hh);
+          const float4 bv = *reinterpret_cast<const float4*>(lds_qcb + 128 * nt + 32 * t + 8 * cc + 4 * hh);
           acc[t][4 * cc] = bv.x; acc[t][4 * cc + 1] = bv.y; acc[t][4 * cc + 2] = bv.z; acc[t][4 * cc + 3] = bv.w;
         }
 #endif
@@ -1010,6 +1034,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         // then stay in flight
         constexpr int TAIL_ST = (GWW_MF_ABL & 3) ? 0 : 8;   // output stores per n-tile in the vmcnt queue
         if (GWW_MF_ABL & 4) {}
+        else if (!LNQ && !(GWW_MF_ABL & 32) && nt == 0 && kt <= MF_AHEAD - 2) {}   // landed before the seam's loads (above)
         else if (nt > 0 && kt <= MF_AHEAD - 2) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + TAIL_ST>();
         else mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
         if (!(GWW_MF_ABL & 8)) __builtin_amdgcn_s_barrier();
@@ -1081,11 +1106,11 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
             const float v0 = acc[t][4 * cc], v1 = acc[t][4 * cc + 1], v2 = acc[t][4 * cc + 2], v3 = acc[t][4 * cc + 3];
             (void)nl;
 #elif GWW_MF_NORM
-            const float4 bv = *reinterpret_cast<const float4*>(lds_cb + nl);
+            const float4 bv = *reinterpret_cast<const float4*>(lds_qcb + nl);
             const float v0 = acc[t][4 * cc] + bv.x, v1 = acc[t][4 * cc + 1] + bv.y;
             const float v2 = acc[t][4 * cc + 2] + bv.z, v3 = acc[t][4 * cc + 3] + bv.w;
 #else
-            const float4 bv = *reinterpret_cast<const float4*>(lds_cb + nl);
+            const float4 bv = *reinterpret_cast<const float4*>(lds_qcb + nl);
             const float4 uv = *reinterpret_cast<const float4*>(lds_u + nl);
             const float v0 = fmaf(row_rstd, fmaf(-row_mean, uv.x, acc[t][4 * cc]), bv.x);
             const float v1 = fmaf(row_rstd, fmaf(-row_mean, uv.y, acc[t][4 * cc + 1]), bv.y);
@@ -1217,6 +1242,7 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
   GWW_REQUIRE(d == MF_D, "mlp_fused: built for d_model = 384 (got %d)", d);
   GWW_REQUIRE(F % 128 == 0 && F > 0 && F <= MF_FMAX, "mlp_fused: ffn = %d must be a multiple of 128, <= 1536", F);
   GWW_REQUIRE((const void*)x_out != (const void*)x, "mlp_fused: x_out must not alias x");
+  GWW_REQUIRE(M * (long)(MF_D * 4) < (1L << 32), "mlp_fused: M = %ld rows exceed the 32-bit row offsets of the seams", M);
   const bool qkv = q_out != nullptr;
   GWW_REQUIRE(qkv || C, "mlp_fused: no output");
   GWW_REQUIRE(!qkv || (q_u && q_cb && NQ > 0 && NQ % 128 == 0 && NQ <= MF_FMAX),
@@ -1232,8 +1258,11 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
   hipLaunchKernelGGL((k_mlp_fused<QQ, OO>), dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta, \
                      x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger, __VA_ARGS__, bo)
   if (qkv) {
-    float* xnx = x_next_out ? x_next_out : x_out;
-    GWW_REQUIRE((((uintptr_t)xnx) & 15) == 0 && (const void*)xnx != (const void*)x, "mlp_fused: bad x_next_out");
+    // x_next goes to its own buffer (training: the saved activations) or back over x, whose rows each workgroup has
+    // finished reading long before it writes them; never over x_out: the seam's unmasked stores of the clamped rows past M
+    // are only harmless while it does not run in place (k_mlp_fused, seam)
+    float* xnx = x_next_out ? x_next_out : const_cast<float*>(x);
+    GWW_REQUIRE((((uintptr_t)xnx) & 15) == 0 && (const void*)xnx != (const void*)x_out, "mlp_fused: x_next must not alias x_out");
     if (bo) GWW_MF_LAUNCH(1, true, q_u, q_cb, (unsigned short*)q_out, NQ, xnx);
     else GWW_MF_LAUNCH(1, false, q_u, q_cb, (unsigned short*)q_out, NQ, xnx);
   } else {
@@ -1291,7 +1320,7 @@ extern "C" int gww_mlp_pack_op_bf16(const void* wo, const void* w1_folded, const
   return launch_mlp_pack(w1_folded, w2, wqkv_folded_or_null, out, d, F, NQ, (hipStream_t)stream, wo);
 }
 
-extern "C" int gww_attn_out_mlp_fused_bf16(const float* x, const void* ctx, const float* bo, float* x_out, const float* ln_u,
+extern "C" int gww_attn_out_mlp_fused_bf16(float* x, const void* ctx, const float* bo, float* x_out, const float* ln_u,
                                            const float* ln_cb, const void* Wt, const float* b2, void* C, long M, int d,
                                            int F, const float* qkv_u, const float* qkv_cb, void* qkv_out, int NQ,
                                            void* stream) {
@@ -1305,7 +1334,7 @@ extern "C" int gww_lnqkv_fused_bf16(const float* x, const float* qkv_u, const fl
   return launch_lnqkv_fused(x, qkv_u, qkv_cb, Wt, qkv_out, M, d, NQ, (hipStream_t)stream);
 }
 
-extern "C" int gww_mlp_fused_bf16(const float* x, const void* delta, float* x_out, const float* ln_u,
+extern "C" int gww_mlp_fused_bf16(float* x, const void* delta, float* x_out, const float* ln_u,
                                   const float* ln_cb, const void* Wt, const float* b2, void* C, long M, int d,
                                   int F, const float* qkv_u, const float* qkv_cb, void* qkv_out, int NQ,
                                   void* stream) {

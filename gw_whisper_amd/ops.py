@@ -221,6 +221,8 @@ def attn_out_mlp_fused(x, ctx, wo, bo, w1_folded, w2, ln_u, ln_cb, b2, qkv=None)
     f = lambda t: _dev(t, torch.float32)
     bo, u, cb, b2 = f(bo), f(ln_u), f(ln_cb), f(b2)
     wt = torch.empty((d * d + 2 * d * F + NQ * d,), dtype=torch.bfloat16, device=x.device)
+    if qkv is not None:
+        x = x.clone()      # the library writes x_next back over x (include/gww.h): the caller's tensor stays untouched
     x_out = torch.empty_like(x)
     with torch.cuda.device(x.device):
         check(lib().gww_mlp_pack_op_bf16(wo.data_ptr(), w1.data_ptr(), w2.data_ptr(), wq.data_ptr() if wq is not None else None,
@@ -238,7 +240,7 @@ def attn_out_mlp_fused(x, ctx, wo, bo, w1_folded, w2, ln_u, ln_cb, b2, qkv=None)
                                                 qc.data_ptr() if qc is not None else None,
                                                 out.data_ptr() if qkv is not None else None, NQ, _stream()),
               "gww_attn_out_mlp_fused_bf16")
-    return out[:M], x_out
+    return out[:M], (x_out if qkv is None else x)
 
 
 def lnqkv_fused(x, wt, qkv_u, qkv_cb):
@@ -266,6 +268,8 @@ def mlp_fused(x, delta, wt, ln_u, ln_cb, b2, qkv=None):
     M, d = x.shape
     F = ln_u.numel()
     Mp = (M + 127) // 128 * 128
+    if qkv is not None:
+        x = x.clone()      # the library writes x_next back over x (include/gww.h): the caller's tensor stays untouched
     x_out = torch.empty_like(x)
     f = lambda t: _dev(t, torch.float32)
     u, cb, b2 = f(ln_u), f(ln_cb), f(b2)
@@ -285,7 +289,7 @@ def mlp_fused(x, delta, wt, ln_u, ln_cb, b2, qkv=None):
                                        qc.data_ptr() if qc is not None else None,
                                        qo.data_ptr() if qo is not None else None, NQ, _stream()),
               "gww_mlp_fused_bf16")
-    return ((c if qkv is None else qo)[:M], x_out)
+    return ((c if qkv is None else qo)[:M], x_out if qkv is None else x)
 
 
 def attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:

@@ -252,16 +252,69 @@ class QTransformAdapter(nn.Module):
         m.load_state_dict(sd)
         return m
 
+    # ---- the CNN as HIP kernels (csrc/qadapter_cnn.hip): the inference path.  Training the adapter (MLGWSC-1/train.py:
+    # 494-504 trains it through the frozen encoder) keeps the torch.nn modules, whose autograd provides the weight / input
+    # gradients; both run the same parameters.
+    def _cnn_params(self):
+        fa = self.freq_adapter
+        return [fa[0].weight, fa[0].bias, fa[3].weight, fa[3].bias, fa[6].weight, fa[6].bias, fa[8].weight, fa[8].bias]
+
+    def _packed_cnn(self):
+        ps = self._cnn_params()
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_cnn_key", None) != key:
+            c1, c2, c3 = (int(ps[i].shape[0]) for i in (0, 2, 4))
+            n = lib().gww_qadapter_cnn_packed_bytes(c1, c2, c3)
+            if n == 0:
+                self._cnn_packed, self._cnn_ch = None, None       # channel widths the kernels are not built for
+            else:
+                dev = ps[0].device
+                blob = torch.empty(n, dtype=torch.uint8, device=dev)
+                f = [p.detach().to(torch.float32).contiguous() for p in ps]
+                with torch.cuda.device(dev):
+                    check(lib().gww_qadapter_cnn_pack_f32(*[t.data_ptr() for t in f], c1, c2, c3, blob.data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream), "gww_qadapter_cnn_pack_f32")
+                self._cnn_packed, self._cnn_ch = blob, (c1, c2, c3)
+            self._cnn_key = key
+        return self._cnn_packed, self._cnn_ch
+
+    def cnn_forward(self, qspec: torch.Tensor) -> torch.Tensor:
+        """``self.freq_adapter(qspec[:, None])[:, 0]`` by the HIP kernels: [B, H, W] fp32 -> [B, H/4, W/4] fp32."""
+        packed, ch = self._packed_cnn()
+        B, H, W = qspec.shape
+        if packed is None or H % 32 or W % 128:
+            raise _lib.GwwError(f"QTransformAdapter: no HIP CNN for channels {ch} on a {H} x {W} map")
+        qspec = qspec.to(torch.float32).contiguous()
+        y = torch.empty((B, H // 4, W // 4), dtype=torch.float32, device=qspec.device)
+        need = lib().gww_qadapter_cnn_workspace_bytes(B, H, W, ch[0], ch[1])
+        ws = getattr(self, "_cnn_ws", None)
+        if ws is None or ws.numel() < need or ws.device != qspec.device:
+            ws = self._cnn_ws = torch.empty(need, dtype=torch.uint8, device=qspec.device)
+        with torch.cuda.device(qspec.device):
+            check(lib().gww_qadapter_cnn_forward_f32(qspec.data_ptr(), B, H, W, packed.data_ptr(), *ch, ws.data_ptr(), ws.numel(),
+                                                     y.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                  "gww_qadapter_cnn_forward_f32")
+        return y
+
+    def _use_hip_cnn(self, x) -> bool:
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False                       # training step: torch autograd through the torch.nn modules
+        return self._packed_cnn()[0] is not None
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, D, _ = x.shape
         F, T = self.target_shape
         if T % 4 != 0:
             raise _lib.GwwError("QTransformAdapter: target_shape[1] must be a multiple of 4")
         out = torch.empty((B, D, F, T), dtype=torch.float32, device=x.device)
+        hip_cnn = self._use_hip_cnn(x)
         for i in range(D):
             with torch.no_grad():
                 qspec = self.q_transform(x[:, i]).unsqueeze(1)        # [B, 1, F, T]  (plane chosen per call, per detector)
-            y = self.freq_adapter(qspec).squeeze(1)                   # small CNN (torch.nn): [B, F', T']
+            if hip_cnn:
+                y = self.cnn_forward(qspec[:, 0])                     # three HIP launches, no library call
+            else:
+                y = self.freq_adapter(qspec).squeeze(1)               # torch.nn (autograd for the adapter's training)
             # final_pool + scale / bias + FiLM and the stack over detectors: one kernel, one 960 KB write per window
             out = _AdapterTail.apply(y, self.scale, self.bias, self.film_gamma, self.film_beta, out, i)
         return out

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GWW_VERSION 103  /* 0.1.3: + gww_logmel_host_f32 (fork-safe CPU twin of the front end); 0.1.2: + whitening kernels, gww_qadapter_tail_f32, gww_attention_bwd_log2q_bf16, gww_lnqkv_fused_bf16, gww_attn_out_mlp_fused_bf16, gww_mlp_pack_op_bf16; the gww_mlp_pack_bf16 stream carries W1 / 8 and 8 W2 */
+#define GWW_VERSION 104  /* 0.1.4: gww_mlp_fused_bf16 / gww_attn_out_mlp_fused_bf16 with the q / k / v tail return x_next over x (x_out keeps x_new); 0.1.3: + gww_logmel_host_f32 (fork-safe CPU twin of the front end); 0.1.2: + whitening kernels, gww_qadapter_tail_f32, gww_attention_bwd_log2q_bf16, gww_lnqkv_fused_bf16, gww_attn_out_mlp_fused_bf16, gww_mlp_pack_op_bf16; the gww_mlp_pack_bf16 stream carries W1 / 8 and 8 W2 */
 
 #define GWW_OK 0
 #define GWW_ERR_ARG (-1)      /* bad argument (shape, null pointer, unsupported size) */
@@ -237,11 +237,12 @@ int gww_gemm_fulln_bf16(const void* A, const void* W, const float* bias, void* C
  * 128.  F % 128 == 0, F <= 1536.  The [M,F] activation never leaves the CU; GELU is x * sigmoid(odd quintic),
  * |err| <= 2.6e-5 against the erf form.
  * With qkv_out != NULL the NEXT layer's self_attn_layer_norm + q / k / v projection (HF:modeling_whisper.py:392,
- * 303-318) is appended: x_out then receives x_next = x + delta + bf16(C) (the residual stream entering the next
- * layer), C is not written, and qkv_out bf16 [M (rows padded to 128), NQ] = LayerNorm(x_next) Wqkv'^T + cb with
+ * 303-318) is appended: x_next = x + delta + bf16(C) (the residual stream entering the next layer) is then written
+ * BACK OVER x (every 128-row panel has finished reading its rows of x by then; x_out keeps x + delta, the block's
+ * intermediate stream -- the kernel's second residual seam must not run in place), C is not written, and qkv_out bf16 [M (rows padded to 128), NQ] = LayerNorm(x_next) Wqkv'^T + cb with
  * qkv_u / qkv_cb from gww_ln_fold_weights of that projection (its panel appended to the stream by
  * gww_mlp_pack_bf16).  NQ % 128 == 0, NQ <= 1536. */
-int gww_mlp_fused_bf16(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
+int gww_mlp_fused_bf16(float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
                        const void* Wt, const float* b2, void* C, long M, int d, int F, const float* qkv_u,
                        const float* qkv_cb, void* qkv_out, int NQ, void* stream);
 /* Pre-tile the weights of gww_mlp_fused_bf16: w1_folded bf16 [F,384] (gww_ln_fold_weights), w2 bf16 [384,F],
@@ -253,7 +254,7 @@ int gww_mlp_pack_bf16(const void* w1_folded, const void* w2, const void* wqkv_fo
  * [M,384] is the attention context, x_out = x + bf16(ctx W_o^T + bo) (the value the stand-alone out_proj + deferred
  * residual add produce), then the block as gww_mlp_fused_bf16 describes, incl. the optional q / k / v tail.  Wt =
  * gww_mlp_pack_op_bf16: the 18 tiles of W_o bf16 [384,384] in front of the gww_mlp_pack_bf16 stream. */
-int gww_attn_out_mlp_fused_bf16(const float* x, const void* ctx, const float* bo, float* x_out, const float* ln_u,
+int gww_attn_out_mlp_fused_bf16(float* x, const void* ctx, const float* bo, float* x_out, const float* ln_u,
                                 const float* ln_cb, const void* Wt, const float* b2, void* C, long M, int d, int F,
                                 const float* qkv_u, const float* qkv_cb, void* qkv_out, int NQ, void* stream);
 int gww_mlp_pack_op_bf16(const void* wo, const void* w1_folded, const void* w2, const void* wqkv_folded_or_null, void* out,
@@ -289,6 +290,23 @@ int gww_qscan_interp_f32(const float* energy, long e_total, const int* rows, con
 int gww_qadapter_tail_f32(const float* y, int B, int Hin, int Win, const float* scale, const float* bias,
                           const float* gamma_i, const float* beta_i, float* out, long out_batch_stride, int F, int T,
                           void* stream);
+/* The adapter's small CNN (`self.freq_adapter`: Conv2d(1,c1,3,p1) ReLU MaxPool2d(2) Conv2d(c1,c2,3,p1) ReLU MaxPool2d(2)
+ * Conv2d(c2,c3,3,p1) ReLU Conv2d(c3,1,1); MLGWSC-1/train.py:117-122 with c = 32 / 64 / 128, MLGWSC-1/inference.py:320-330
+ * with c = 16 / 32 / 64) as three HIP launches: a VALU kernel for the one-channel input layer and an implicit-GEMM MFMA
+ * kernel (bf16-pair operands, fp32 accumulation: about 1e-5 relative to the fp32 the reference computes in) with ReLU /
+ * max-pool resp. ReLU + the 1 x 1 convolution in its epilogue.
+ *   gww_qadapter_cnn_pack_f32: the torch parameters (device fp32: w1 [c1,1,3,3] b1 [c1] w2 [c2,c1,3,3] b2 [c2]
+ *     w3 [c3,c2,3,3] b3 [c3] w4 [1,c3,1,1] b4 [1]) -> `packed` (gww_qadapter_cnn_packed_bytes bytes; 0 = channel widths
+ *     the reference does not have)
+ *   gww_qadapter_cnn_forward_f32: qspec fp32 [B, H, W] (the Q-scan map, H % 32 == 0, W % 128 == 0) -> y fp32
+ *     [B, H/4, W/4] (the input of gww_qadapter_tail_f32); workspace: gww_qadapter_cnn_workspace_bytes, caller-owned */
+size_t gww_qadapter_cnn_packed_bytes(int c1, int c2, int c3);
+size_t gww_qadapter_cnn_workspace_bytes(int B, int H, int W, int c1, int c2);
+int gww_qadapter_cnn_pack_f32(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                              const float* b3, const float* w4, const float* b4, int c1, int c2, int c3, void* packed,
+                              void* stream);
+int gww_qadapter_cnn_forward_f32(const float* qspec, int B, int H, int W, const void* packed, int c1, int c2, int c3,
+                                 void* workspace, size_t workspace_bytes, float* y, void* stream);
 /* Whitening of the search pipeline's strain (MLGWSC-1/inference.py:56-137 -> PyCBC 2.4.0 TimeSeries.psd / welch /
  * inverse_spectrum_truncation; PARITY UNPINNED -- PyCBC is not installed, the kernels follow oracle/whiten.py).
  * gww_welch_power_f32: |rDFT|^2 * scale of the windowed Welch segments from their (re, im) rows (a gww_gemm_f32 against

@@ -116,3 +116,55 @@ def test_adapter_tail_kernel_matches_the_torch_composition(T, gww, Hin, Win):
     g_ref = T.autograd.grad((ref * w).sum(), leaves)
     for a, b in zip(g_hip, g_ref):
         assert (a - b).abs().max().item() < 2e-3 * (b.abs().max().item() + 1e-6), (a.shape, (a - b).abs().max().item())
+
+
+@pytest.mark.parametrize("variant,n,hw", [("inference", 3, 512), ("train", 5, 128), ("inference", 2, 128)])
+def test_adapter_cnn_kernels_match_the_fp64_torch_cnn(T, gww, variant, n, hw):
+    """csrc/qadapter_cnn.hip (conv1 VALU kernel + two implicit-GEMM MFMA kernels, bf16-pair operands) against the SAME
+    torch.nn stack run in fp64 on the CPU -- the arithmetic of `self.freq_adapter` (MLGWSC-1/train.py:117-122,
+    inference.py:320-330), which the reference computes in fp32.  Bound: 1e-4 of the output scale (round-2 verdict, item 6);
+    the map has the dynamic range of a real Q-scan (a few loud tiles over a unit-mean floor)."""
+    from gw_whisper_amd.qscan import QTransformAdapter
+    T.manual_seed(11 + n)
+    ad = (QTransformAdapter.inference_variant() if variant == "inference" else QTransformAdapter.train_variant()).cuda()
+    with T.no_grad():
+        for p in ad.freq_adapter.parameters():            # away from the initialisation's symmetric tiny biases
+            p.mul_(1.5).add_(0.02 * T.randn_like(p))
+    g = T.Generator().manual_seed(5)
+    q = T.rand(n, hw, hw, generator=g, dtype=T.float64) * 2.0
+    q[:, hw // 3: hw // 3 + 7, hw // 2: hw // 2 + 40] += 60.0            # a loud track
+    q[0, 0, :] = 25.0                                                       # borders: the zero padding must be the conv's
+    q[-1, :, -1] = 30.0
+    ref = ad.freq_adapter.double().cpu()(q[:, None])[:, 0]
+    ad.freq_adapter.float().cuda()
+    with T.no_grad():
+        got = ad.cnn_forward(q.float().cuda())
+    T.cuda.synchronize()
+    assert got.shape == ref.shape == (n, hw // 4, hw // 4)
+    err = (got.double().cpu() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    print(f"adapter CNN [{variant}, {hw}^2]: max |err| {err:.3e} of scale {scale:.3f} ({err / scale:.2e})")
+    assert err < 1e-4 * scale
+
+
+def test_adapter_forward_runs_the_hip_cnn_without_autograd_and_torch_with(T, gww):
+    """Inference (no_grad / nothing trainable) takes the HIP CNN, a training step the torch.nn modules: same numbers."""
+    from gw_whisper_amd.qscan import QTransformAdapter
+    T.manual_seed(3)
+    ad = QTransformAdapter.train_variant().cuda()
+    x = T.from_numpy(_signals(4, 9).astype(np.float32)).cuda().reshape(2, 2, 2048)
+    assert not ad._use_hip_cnn(x)                          # parameters require grad, autograd on
+    y_torch = ad(x)
+    assert y_torch.requires_grad
+    with T.no_grad():
+        assert ad._use_hip_cnn(x)
+        y_hip = ad(x)
+    assert y_hip.shape == y_torch.shape == (2, 2, 80, 3000)
+    err = (y_hip - y_torch.detach()).abs().max().item()
+    scale = y_torch.detach().abs().max().item()
+    print(f"adapter forward: HIP CNN vs torch.nn (fp32) {err:.3e} of {scale:.3f}")
+    assert err < 2e-4 * scale
+    with T.no_grad():                                      # a parameter update re-packs the kernels' weights
+        ad.freq_adapter[3].weight.mul_(1.25)
+        y2 = ad(x)
+    assert (y2 - y_hip).abs().max().item() > 1e-6

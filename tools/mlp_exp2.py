@@ -50,12 +50,17 @@ a, b = t(make(False)), t(make(True))
 print("op+mlp %%.4f (min %%.4f) ms   op+mlp+qkv %%.4f (min %%.4f) ms" %% (a[0], a[1], b[0], b[1]))
 ''' % ROOT
 for m in masks:
-    tag = m.replace("=", "").replace(",", "_").replace("+", "").replace("-", "")
-    defs = [kv[1:] if kv.startswith("+") else f"-DGWW_MF_{kv}" for kv in m.split(",")]
+    tag = m.replace("=", "").replace(",", "_").replace("+", "").replace("-", "").replace(".", "_")
+    src = "mlp_fused.hip"
+    parts = []
+    for kv in m.split(","):
+        if kv.startswith("SRC="): src = kv[4:]      # another source file of csrc/ (an A/B against a saved earlier version)
+        else: parts.append(kv)
+    defs = [kv[1:] if kv.startswith("+") else f"-DGWW_MF_{kv}" for kv in parts]
     o = os.path.join(out, f"mlp_fused_{tag}.o")
     so = os.path.join(out, f"libgww_{tag}.so")
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast", "-mllvm",
-                    "-pragma-unroll-threshold=4000000", *defs, "-c", os.path.join(csrc, "mlp_fused.hip"), "-o", o], check=True)
+                    "-pragma-unroll-threshold=4000000", *defs, "-c", os.path.join(csrc, src), "-o", o], check=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + [o], check=True)
     r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, GWW_LIB=so), capture_output=True, text=True)
     print(f"{m}: {r.stdout.strip()} {r.stderr.strip()[-400:] if r.returncode else ''}", flush=True)
