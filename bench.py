@@ -453,8 +453,8 @@ def main():
             "frontend_qscan": {"kernel": "rDFT GEMM + k_qscan_tiles + k_qscan_interp (parity unpinned, DESIGN.md section 2)",
                                "ms_per_batch": q_ms, "windows_per_s": 2 * B / q_ms * 1e3,
                                "config": f"{2 * B} x 2048 samples, qrange [4, 128], 148 tiles rows, 128 x 128 output"},
-            "q_adapter": {"what": f"QTransformAdapter forward on {B} two-detector windows -> [B, 2, 80, 3000] (Q-scan + torch.nn "
-                                  "CNN + gww_qadapter_tail_f32)", "ms_per_batch": adapter_ms,
+            "q_adapter": {"what": f"QTransformAdapter forward on {B} two-detector windows -> [B, 2, 80, 3000] (Q-scan + the CNN's "
+                                  "three HIP launches, csrc/qadapter_cnn.hip + gww_qadapter_tail_f32; no library call)", "ms_per_batch": adapter_ms,
                           "tail_kernel_ms_per_detector": tail_ms,
                           "tail_kernel_algorithmic_gbs": B * (80 * 3000 + 32 * 32) * 4 / tail_ms / 1e6,
                           "tail_kernel_frac_of_hbm_peak": B * (80 * 3000 + 32 * 32) * 4 / tail_ms / 1e6 / HBM_PEAK_GBS},
@@ -487,12 +487,14 @@ def main():
                 # out = 16 B per element (a second write of the residual stream is NOT algorithmic: it shows up as
                 # pmc_hbm_bytes / algorithmic bytes > 1)
                 "mlp_fused+next_ln_qkv": (B * (4 * T_TOK * d * ffn + 2 * T_TOK * d * 3 * d), M * d * 16),
+                # the last block with the final LayerNorm as its epilogue: x 4 B + ctx 2 B in, last_hidden_state 4 B out
+                "mlp_fused+final_layernorm": (B * 4 * T_TOK * d * ffn, M * d * 10),
             }
             if not traced.get("out_proj", (0, 0))[1] and args.precision == "bf16" and d == 384:
                 # out_proj is fused in front of the MLP block (k_mlp_fused<., true>): its FLOPs and bytes belong to that
                 # launch -- ctx 2 B in instead of the bf16 delta (2 B), nothing else changes at the HBM boundary
                 op = B * 2 * T_TOK * d * d
-                for k in ("mlp_fused(ln+fc1+gelu+fc2)", "mlp_fused+next_ln_qkv"):
+                for k in ("mlp_fused(ln+fc1+gelu+fc2)", "mlp_fused+next_ln_qkv", "mlp_fused+final_layernorm"):
                     work[k] = (work[k][0] + op, work[k][1])
             rows = []
             for name, (ms, cnt) in traced.items():

@@ -105,6 +105,7 @@ SIGNATURES = {
     "gww_mlp_pack_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gww_attn_out_mlp_fused_bf16": (C.c_int, [C.c_void_p] * 9 + [C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_int, C.c_void_p]),
+    "gww_attn_out_mlp_final_bf16": (C.c_int, [C.c_void_p] * 11 + [C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "gww_mlp_pack_op_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gww_lnqkv_fused_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int,
                                        C.c_void_p]),

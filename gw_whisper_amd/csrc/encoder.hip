@@ -35,6 +35,9 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
                      const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s,
                      const float* q_u = nullptr, const float* q_cb = nullptr, void* q_out = nullptr, int NQ = 0,
                      float* x_next_out = nullptr, const float* bo = nullptr);
+int launch_mlp_fused_final(const float* x, const void* ctx, float* x_mid, const float* ln_u, const float* ln_cb,
+                           const void* Wt, const float* b2, const float* bo, const float* lnf_w, const float* lnf_b, float* y,
+                           long M, int d, int F, hipStream_t s);
 int launch_lnqkv_fused(const float* x, const float* q_u, const float* q_cb, const void* Wt, void* q_out, long M, int d,
                        int NQ, hipStream_t s);
 int launch_add_delta_f32(const float* x, const void* delta_bf16, float* out, long n, hipStream_t s);
@@ -81,7 +84,7 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 }  // namespace
 
 // kernel classes of one forward, for the optional per-kernel event trace (bench.py roofline)
-enum : int { TR_MEL = 0, TR_CONV1, TR_CONV2, TR_QKV, TR_ATTN, TR_OUT, TR_FC1, TR_FC2, TR_LN, TR_MLP, TR_MLPQKV, TR_LNROWS, TR_COUNT };
+enum : int { TR_MEL = 0, TR_CONV1, TR_CONV2, TR_QKV, TR_ATTN, TR_OUT, TR_FC1, TR_FC2, TR_LN, TR_MLP, TR_MLPQKV, TR_LNROWS, TR_MLPFIN, TR_COUNT };
 
 struct TraceSpan { int cls; hipEvent_t a, b; };
 
@@ -244,7 +247,7 @@ extern "C" int gww_encoder_trace_classes(void) { return TR_COUNT; }
 extern "C" const char* gww_encoder_trace_class_name(int i) {
   static const char* names[TR_COUNT] = {"mel_to_tokens", "conv1_gelu", "conv2_gelu_pos", "ln+qkv_proj", "attention",
                                         "out_proj", "ln+fc1_gelu", "fc2", "final_layernorm", "mlp_fused(ln+fc1+gelu+fc2)",
-                                        "mlp_fused+next_ln_qkv", "layernorm_rows(B pooled rows)"};
+                                        "mlp_fused+next_ln_qkv", "layernorm_rows(B pooled rows)", "mlp_fused+final_layernorm"};
   return (i >= 0 && i < TR_COUNT) ? names[i] : "?";
 }
 
@@ -586,6 +589,18 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
         pending = nullptr;
         qkv_done = true;
         continue;
+      }
+      static const bool fuse_final = !(getenv("GWW_GENERIC_PATH") && (atoi(getenv("GWW_GENERIC_PATH")) & 256));   // bit 8: stand-alone final LayerNorm
+      if (mlp_fused && op && fuse_final && i == e->cfg.n_layers - 1 && last_hidden) {
+        // the LAST block with the encoder's final LayerNorm as its epilogue: last_hidden_state comes straight out of the
+        // kernel (no bf16 delta, no second read of the residual stream, no LayerNorm launch); the pooled token is row
+        // T - 1 of it
+        TR(TR_MLPFIN, launch_mlp_fused_final(xc, ctx, xn, L.u1, L.cb1, L.wmlp_op, L.b2, L.bo, e->lnw, e->lnb, last_hidden, M, d,
+                                             F, s));
+        if (last_token)
+          GWW_HIP(hipMemcpy2DAsync(last_token, (size_t)d * 4, last_hidden + (size_t)(T - 1) * d, (size_t)T * d * 4, (size_t)d * 4,
+                                   B, hipMemcpyDeviceToDevice, s));
+        return GWW_OK;
       }
       if (mlp_fused) {
         // LN2 + fc1 + GELU + fc2 in one kernel: the [M, ffn] activation never leaves the CU

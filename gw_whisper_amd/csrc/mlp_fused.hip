@@ -178,7 +178,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
                                                             unsigned short* __restrict__ q_out, int NQ,
                                                             float* x_next, const float* __restrict__ bo) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[MF_LDS];
-  constexpr bool QKV = MODE >= 1, LNQ = MODE == 2;
+  constexpr bool QKV = MODE == 1 || MODE == 2, LNQ = MODE == 2, FIN = MODE == 3;
   constexpr int MF_NST = MF_AHEAD + 1;
   float* lds_cb = reinterpret_cast<float*>(lds + MF_OFF_CB);
   float* lds_u = reinterpret_cast<float*>(lds + MF_OFF_U);
@@ -245,6 +245,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     for (int i = tid; i < MF_D; i += MF_THREADS) lds_b2[i] = b2[i];
   if (OP)
     for (int i = tid; i < MF_D; i += MF_THREADS) lds_bo[i] = bo[i];
+  if (FIN)   // gain / bias of the encoder's final LayerNorm (q_u / q_cb carry them in this mode), in the unused u table
+    for (int i = tid; i < MF_D; i += MF_THREADS) { lds_u[i] = q_u[i]; lds_u[MF_D + i] = q_cb[i]; }
   if (QKV && GWW_MF_NORM)   // (a load issued behind the second seam's stores would wait for them: staged here, 6 KB of LDS)
     for (int i = tid; i < NQ; i += MF_THREADS) lds_qcb[i] = q_cb[i];
   // De-phase the first round of workgroups (later ones inherit the offsets as CUs free up): panels take
@@ -962,7 +964,106 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
                  : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]), "+a"(oacc[3]), "+a"(oacc[4]), "+a"(oacc[5]), "+a"(oacc[6]),
                    "+a"(oacc[7]), "+a"(oacc[8]), "+a"(oacc[9]), "+a"(oacc[10]), "+a"(oacc[11]));
   }   // ======== !LNQ
-  if constexpr (!QKV) {
+  if constexpr (FIN) {
+    // ---- MODE 3, the LAST block of the encoder: the epilogue is the final LayerNorm (HF:modeling_whisper.py:642).
+    // x_fin = x_new + bf16(fc2 output + b2) is formed exactly as the second seam forms x_next (same roundings as the
+    // stand-alone delta + LayerNorm kernels), but all 48 row pieces of the panel stay in registers -- the accumulator
+    // tiles free 32 registers per chunk, a chunk's pieces take 32 -- until the row statistics are complete; then
+    // y = (x_fin - mean) rstd g + b goes straight to last_hidden_state.  The bf16 delta (0.3 GB per launch at B = 256),
+    // its re-read, the second read of the residual stream and the LayerNorm launch disappear.
+    mf_wait_vmcnt<0>();   // the ring's re-reads issued past the end
+    float* y_out = reinterpret_cast<float*>(C);
+    unsigned roff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) roff[i] = (unsigned)grow[i] * (unsigned)(MF_D * 4) + 16u * (unsigned)cchunk;
+    f32x4 xh[MF_KT][2][4];
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, cshift[4];
+    auto request = [&](int np0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (np0 == 0)
+              asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" MF_NT
+                           : "=v"(xh[q][h2][i]) : "v"(roff[i]), "s"(x_out), "n"((64 * q + 32 * h2) * 4) : "memory");
+            else
+              asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" MF_NT
+                           : "=a"(xh[3 + q][h2][i]) : "v"(roff[i]), "s"(x_out), "n"((64 * (3 + q) + 32 * h2) * 4) : "memory");
+          }
+    };
+    request(0);
+#pragma unroll
+    for (int np = 0; np < MF_KT; ++np) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * np + tt;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int nl = 32 * t + 8 * cc + 4 * hh;
+          const float4 bv = *reinterpret_cast<const float4*>(lds_b2 + nl);
+          u32x2 o = {pack2bf(oacc[t][4 * cc] + bv.x, oacc[t][4 * cc + 1] + bv.y),
+                     pack2bf(oacc[t][4 * cc + 2] + bv.z, oacc[t][4 * cc + 3] + bv.w)};
+          *reinterpret_cast<u32x2*>(slice + r * MF_SLICE_STRIDE + (32 * tt + 8 * cc + 4 * hh) * 2) = o;
+        }
+      }
+      if (np == 2) request(3);   // into the accumulator registers chunks 0 .. 2 have just freed
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // load k = 8 (np % 3) + 4 h2 + i of its batch; batch 1 is requested in front of chunk 2's waits: its 24 loads
+          // are younger than every load of batch 0 still outstanding then
+          if (np < 2) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xh[np][h2][i]) : "n"(23 - (8 * np + 4 * h2 + i)));
+          else if (np == 2) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xh[np][h2][i]) : "n"(24 + 23 - (16 + 4 * h2 + i)));
+          else asm volatile("s_waitcnt vmcnt(%1)" : "+a"(xh[np][h2][i]) : "n"(23 - (8 * (np - 3) + 4 * h2 + i)));
+          f32x4 v = xh[np][h2][i];
+          const u32x2 dv = *reinterpret_cast<const u32x2*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + h2 * 64 + cchunk * 8);
+          v[0] += bf2f((unsigned short)(dv[0] & 0xffff));
+          v[1] += bf2f((unsigned short)(dv[0] >> 16));
+          v[2] += bf2f((unsigned short)(dv[1] & 0xffff));
+          v[3] += bf2f((unsigned short)(dv[1] >> 16));
+          if (np == 0 && h2 == 0) {
+            float t = (v[0] + v[1]) + (v[2] + v[3]);
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            cshift[i] = t * (1.0f / 32.0f);
+          }
+          v[0] -= cshift[i]; v[1] -= cshift[i]; v[2] -= cshift[i]; v[3] -= cshift[i];
+          s1[i] += (v[0] + v[1]) + (v[2] + v[3]);
+          s2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          xh[np][h2][i] = v;      // x_fin - shift, kept until the statistics are complete
+        }
+    }
+    float rstd[4], mean_s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = s1[i], b = s2[i];
+      a += __shfl_xor(a, 1, 64); b += __shfl_xor(b, 1, 64);
+      a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64);
+      a += __shfl_xor(a, 4, 64); b += __shfl_xor(b, 4, 64);
+      mean_s[i] = a * (1.0f / MF_D);
+      rstd[i] = rsqrtf(fmaxf(b * (1.0f / MF_D) - mean_s[i] * mean_s[i], 0.f) + 1e-5f);
+    }
+#pragma unroll
+    for (int np = 0; np < MF_KT; ++np)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int col = 64 * np + 32 * h2 + 4 * cchunk;
+        const float4 g4 = *reinterpret_cast<const float4*>(lds_u + col);
+        const float4 b4 = *reinterpret_cast<const float4*>(lds_u + MF_D + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4 v = xh[np][h2][i];
+          const f32x4 y = {fmaf((v[0] - mean_s[i]) * rstd[i], g4.x, b4.x), fmaf((v[1] - mean_s[i]) * rstd[i], g4.y, b4.y),
+                           fmaf((v[2] - mean_s[i]) * rstd[i], g4.z, b4.z), fmaf((v[3] - mean_s[i]) * rstd[i], g4.w, b4.w)};
+          // rows past M are clamped duplicates of row M - 1: every duplicate stores the same value (y_out != x_out)
+          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(y_out) + roff[i] + (64 * np + 32 * h2) * 4) = y;
+        }
+      }
+  } else if constexpr (!QKV) {
     mf_wait_vmcnt<0>();   // the re-reads issued past the end
     // ---- epilogue: + b2 -> bf16 -> wave-private LDS transpose -> whole-line stores
 #pragma unroll
@@ -1274,6 +1375,27 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
   return GWW_OK;
 }
 
+// The LAST block of the encoder with the final LayerNorm as its epilogue (k_mlp_fused<3, true>): ctx bf16 [M, 384] and x fp32
+// [M, 384] in, y fp32 [M, 384] = LayerNorm_final(x + bf16(ctx W_o^T + bo) + bf16(mlp(...) + b2)) out; x_mid (fp32 [M, 384],
+// != x, != y) receives the block's intermediate residual stream.  Wt = launch_mlp_pack(w1_folded, w2, NULL, ., wo).
+int launch_mlp_fused_final(const float* x, const void* ctx, float* x_mid, const float* ln_u, const float* ln_cb,
+                           const void* Wt, const float* b2, const float* bo, const float* lnf_w, const float* lnf_b, float* y,
+                           long M, int d, int F, hipStream_t s) {
+  GWW_REQUIRE(x && ctx && x_mid && ln_u && ln_cb && Wt && b2 && bo && lnf_w && lnf_b && y, "mlp_fused_final: NULL operand");
+  GWW_REQUIRE(d == MF_D, "mlp_fused_final: built for d_model = 384 (got %d)", d);
+  GWW_REQUIRE(F % 128 == 0 && F > 0 && F <= MF_FMAX, "mlp_fused_final: ffn = %d must be a multiple of 128, <= 1536", F);
+  GWW_REQUIRE((const void*)x_mid != (const void*)x && (const void*)y != (const void*)x_mid, "mlp_fused_final: x_mid must alias neither x nor y");
+  GWW_REQUIRE(M * (long)(MF_D * 4) < (1L << 32), "mlp_fused_final: M = %ld rows exceed the 32-bit row offsets of the seams", M);
+  GWW_REQUIRE(((((uintptr_t)x) | ((uintptr_t)ctx) | ((uintptr_t)x_mid) | ((uintptr_t)Wt) | ((uintptr_t)y)) & 15) == 0,
+              "mlp_fused_final: operands must be 16-byte aligned");
+  if (M == 0) return GWW_OK;
+  hipLaunchKernelGGL((k_mlp_fused<3, true>), dim3((unsigned)cdiv(M, MF_BM)), dim3(MF_THREADS), 0, s, x, (const unsigned short*)ctx,
+                     x_mid, ln_u, ln_cb, (const unsigned short*)Wt, b2, reinterpret_cast<unsigned short*>(y), M, F, 0, lnf_w,
+                     lnf_b, (unsigned short*)nullptr, 0, (float*)nullptr, bo);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
 // LayerNorm + q / k / v projection of a residual stream WITHOUT a pending delta (layer 0): q_out bf16 [>= roundup(M, 128),
 // NQ] = LN(x) Wqkv'^T + cb with the LayerNorm folded into Wt = launch_mlp_pack(NULL, NULL, wqkv_folded, ., 384, 0, NQ)
 // and q_u / q_cb (gww_ln_fold_weights).  x is only read.
@@ -1327,6 +1449,12 @@ extern "C" int gww_attn_out_mlp_fused_bf16(float* x, const void* ctx, const floa
   GWW_REQUIRE(bo, "gww_attn_out_mlp_fused_bf16: NULL out_proj bias");
   return launch_mlp_fused(x, ctx, x_out, ln_u, ln_cb, Wt, b2, C, M, d, F, (hipStream_t)stream, qkv_u, qkv_cb, qkv_out, NQ,
                           nullptr, bo);
+}
+
+extern "C" int gww_attn_out_mlp_final_bf16(const float* x, const void* ctx, const float* bo, float* x_mid, const float* ln_u,
+                                          const float* ln_cb, const void* Wt, const float* b2, const float* lnf_w,
+                                          const float* lnf_b, float* y, long M, int d, int F, void* stream) {
+  return launch_mlp_fused_final(x, ctx, x_mid, ln_u, ln_cb, Wt, b2, bo, lnf_w, lnf_b, y, M, d, F, (hipStream_t)stream);
 }
 
 extern "C" int gww_lnqkv_fused_bf16(const float* x, const float* qkv_u, const float* qkv_cb, const void* Wt, void* qkv_out,

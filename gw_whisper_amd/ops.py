@@ -243,6 +243,27 @@ def attn_out_mlp_fused(x, ctx, wo, bo, w1_folded, w2, ln_u, ln_cb, b2, qkv=None)
     return out[:M], (x_out if qkv is None else x)
 
 
+def attn_out_mlp_final(x, ctx, wo, bo, w1_folded, w2, ln_u, ln_cb, b2, lnf_w, lnf_b):
+    """The LAST block with the encoder's final LayerNorm as its epilogue (``gww_attn_out_mlp_final_bf16``): returns
+    (y fp32 [M, 384] = LayerNorm_final(x_mid + bf16(mlp(LayerNorm2(x_mid)) + b2)), x_mid = x + bf16(ctx Wo^T + bo))."""
+    x = _dev(x, torch.float32, "x")
+    ctx = _dev(ctx, torch.bfloat16, "ctx")
+    wo, w1, w2 = _dev(wo, torch.bfloat16, "Wo"), _dev(w1_folded, torch.bfloat16, "W1"), _dev(w2, torch.bfloat16, "W2")
+    F, d = w1.shape
+    M = x.shape[0]
+    f = lambda t: _dev(t, torch.float32)
+    bo, u, cb, b2, lw, lb = f(bo), f(ln_u), f(ln_cb), f(b2), f(lnf_w), f(lnf_b)
+    wt = torch.empty((d * d + 2 * d * F,), dtype=torch.bfloat16, device=x.device)
+    x_mid, y = torch.empty_like(x), torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib().gww_mlp_pack_op_bf16(wo.data_ptr(), w1.data_ptr(), w2.data_ptr(), None, wt.data_ptr(), d, F, 0, _stream()),
+              "gww_mlp_pack_op_bf16")
+        check(lib().gww_attn_out_mlp_final_bf16(x.data_ptr(), ctx.data_ptr(), bo.data_ptr(), x_mid.data_ptr(), u.data_ptr(),
+                                                cb.data_ptr(), wt.data_ptr(), b2.data_ptr(), lw.data_ptr(), lb.data_ptr(),
+                                                y.data_ptr(), M, d, F, _stream()), "gww_attn_out_mlp_final_bf16")
+    return y, x_mid
+
+
 def lnqkv_fused(x, wt, qkv_u, qkv_cb):
     """qkv bf16 [M, NQ] = LayerNorm(x) Wqkv'^T + cb for a residual stream without a pending delta (layer 0): the panel
     prologue and the q / k / v tail of the fused MLP kernel; ``wt = mlp_pack(None, None, wqkv_folded)``."""

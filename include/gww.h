@@ -257,6 +257,12 @@ int gww_mlp_pack_bf16(const void* w1_folded, const void* w2, const void* wqkv_fo
 int gww_attn_out_mlp_fused_bf16(float* x, const void* ctx, const float* bo, float* x_out, const float* ln_u,
                                 const float* ln_cb, const void* Wt, const float* b2, void* C, long M, int d, int F,
                                 const float* qkv_u, const float* qkv_cb, void* qkv_out, int NQ, void* stream);
+/* ... and, for the LAST layer, with the encoder's final LayerNorm (HF:modeling_whisper.py:642) as the epilogue:
+ * y fp32 [M,384] = LayerNorm(x_mid + bf16(mlp(LayerNorm2(x_mid)) + b2); lnf_w, lnf_b), x_mid = x + bf16(ctx W_o^T + bo)
+ * (x_mid fp32 [M,384] is written too; it aliases neither x nor y).  Wt = gww_mlp_pack_op_bf16 without a q / k / v panel. */
+int gww_attn_out_mlp_final_bf16(const float* x, const void* ctx, const float* bo, float* x_mid, const float* ln_u,
+                                const float* ln_cb, const void* Wt, const float* b2, const float* lnf_w, const float* lnf_b,
+                                float* y, long M, int d, int F, void* stream);
 int gww_mlp_pack_op_bf16(const void* wo, const void* w1_folded, const void* w2, const void* wqkv_folded_or_null, void* out,
                          int d, int F, int NQ, void* stream);
 /* self_attn_layer_norm + q / k / v projection of a residual stream with no pending delta (layer 0, fed by the conv stem;

@@ -499,6 +499,80 @@ def test_attn_out_mlp_fused(T, gww, M, with_qkv):
     assert np.sqrt(((a - b) ** 2).mean()) < 8e-3
 
 
+def _block_operands(rng, M, d=384, F=1536, NQ=1152):
+    x = (rng.standard_normal((M, d)) * 2 + 0.3).astype(np.float32)
+    x[::7] += 25.0
+    g = lambda n: (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    sm = lambda n: (0.1 * rng.standard_normal(n)).astype(np.float32)
+    return dict(x=x, ctx=_bf(rng.standard_normal((M, d))), wo=_bf(rng.standard_normal((d, d)) / np.sqrt(d)),
+                bo=rng.standard_normal(d).astype(np.float32), lw=g(d), lb=sm(d), lw1=g(d), lb1=sm(d),
+                w1=(rng.standard_normal((F, d)) / np.sqrt(d)).astype(np.float32), b1=rng.standard_normal(F).astype(np.float32),
+                w2=_bf(rng.standard_normal((d, F)) / np.sqrt(F)), b2=rng.standard_normal(d).astype(np.float32),
+                wq=(rng.standard_normal((NQ, d)) / np.sqrt(d)).astype(np.float32), bq=rng.standard_normal(NQ).astype(np.float32))
+
+
+def _block_fp64(o):
+    """x_mid, the bf16-rounded MLP delta and x_next of one block in fp64 (HF:modeling_whisper.py:396-407)."""
+    delta1 = _bf(o["ctx"].astype(np.float64) @ o["wo"].astype(np.float64).T + o["bo"]).astype(np.float64)
+    x_mid = o["x"].astype(np.float64) + delta1
+    h = oenc.gelu(oenc.layer_norm(x_mid, o["lw"], o["lb"]) @ o["w1"].astype(np.float64).T + o["b1"])
+    mlp = h @ o["w2"].astype(np.float64).T + o["b2"]
+    return x_mid, mlp
+
+
+@pytest.mark.parametrize("M", [128, 1500, 777, 9000])
+def test_attn_out_mlp_qkv_fused_against_fp64(T, gww, M):
+    """The dominant kernel of the forward, k_mlp_fused<1, true> (out_proj + LN2 + fc1 + GELU + fc2 + next LN1 + q/k/v),
+    against fp64 end to end (round-2 review: its outputs had only been compared with other HIP kernels): x_next to the
+    bf16 rounding of the two deltas, q/k/v to bf16 operand + output rounding of LayerNorm_1(x_next) Wqkv^T + b."""
+    from gw_whisper_amd import ops
+    o = _block_operands(np.random.default_rng(M + 11), M)
+    c = lambda a: T.from_numpy(np.asarray(a)).cuda()
+    w1f, u, cb = ops.ln_fold_weights(c(o["w1"]), c(o["lw"]), c(o["lb"]), c(o["b1"]))
+    wqf, uq, cq = ops.ln_fold_weights(c(o["wq"]), c(o["lw1"]), c(o["lb1"]), c(o["bq"]))
+    x_dev = c(o["x"])
+    qkv, x_next = ops.attn_out_mlp_fused(x_dev, c(o["ctx"]).bfloat16(), c(o["wo"]).bfloat16(), c(o["bo"]), w1f,
+                                         c(o["w2"]).bfloat16(), u, cb, c(o["b2"]), qkv=(wqf, uq, cq))
+    assert T.equal(x_dev, c(o["x"]))                       # the wrapper hands the library a copy: x_next comes back over it
+    x_mid, mlp = _block_fp64(o)
+    x_next_ref = x_mid + mlp
+    got_x = x_next.cpu().numpy().astype(np.float64)
+    # each delta is rounded to bf16 before it is added (8 bits) and was computed from bf16 operands
+    tol_x = np.abs(mlp) * 2.0 ** -7 + np.abs(x_mid - o["x"]) * 2.0 ** -7 + 4e-2
+    assert (np.abs(got_x - x_next_ref) <= tol_x).all(), np.abs(got_x - x_next_ref).max()
+    assert np.sqrt(((got_x - x_next_ref) ** 2).mean()) < 8e-3
+    ref = oenc.layer_norm(got_x, o["lw1"], o["lb1"]) @ o["wq"].astype(np.float64).T + o["bq"]
+    got = qkv.float().cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=3e-2, rtol=2 ** -7)
+    assert np.sqrt(((got - ref) ** 2).mean()) < 6e-3
+
+
+@pytest.mark.parametrize("M", [128, 1500, 777, 9000])
+def test_attn_out_mlp_final_layernorm_against_fp64(T, gww, M):
+    """k_mlp_fused<3, true>: the LAST block with the encoder's final LayerNorm as its epilogue
+    (HF:modeling_whisper.py:396-407, 642) against fp64; the fp32 output replaces delta + stand-alone LayerNorm."""
+    from gw_whisper_amd import ops
+    o = _block_operands(np.random.default_rng(M + 23), M)
+    c = lambda a: T.from_numpy(np.asarray(a)).cuda()
+    w1f, u, cb = ops.ln_fold_weights(c(o["w1"]), c(o["lw"]), c(o["lb"]), c(o["b1"]))
+    y, x_mid_dev = ops.attn_out_mlp_final(c(o["x"]), c(o["ctx"]).bfloat16(), c(o["wo"]).bfloat16(), c(o["bo"]), w1f,
+                                          c(o["w2"]).bfloat16(), u, cb, c(o["b2"]), c(o["lw1"]), c(o["lb1"]))
+    x_mid, mlp = _block_fp64(o)
+    assert np.abs(x_mid_dev.cpu().numpy() - x_mid).max() <= np.abs(x_mid - o["x"]).max() * 2.0 ** -7 + 1e-3
+    # what the unfused path computes: LayerNorm(x_mid + bf16(mlp)) -- the kernel's own x_mid and delta rounding
+    ref = oenc.layer_norm(x_mid_dev.cpu().numpy().astype(np.float64) + mlp, o["lw1"], o["lb1"])
+    got = y.cpu().numpy().astype(np.float64)
+    # the delta carries bf16 rounding (2^-8 relative) and bf16-operand error; LayerNorm divides by the row's sigma (~2.5)
+    np.testing.assert_allclose(got, ref, atol=3e-2, rtol=0)
+    assert np.sqrt(((got - ref) ** 2).mean()) < 4e-3
+    # ... and bit for bit what the stand-alone kernels give on the same operands: the bf16 delta + the LayerNorm kernel
+    delta, x_mid2 = ops.attn_out_mlp_fused(c(o["x"]), c(o["ctx"]).bfloat16(), c(o["wo"]).bfloat16(), c(o["bo"]), w1f,
+                                           c(o["w2"]).bfloat16(), u, cb, c(o["b2"]))
+    assert T.equal(x_mid2, x_mid_dev)
+    unfused = ops.layernorm(x_mid2 + delta.float(), c(o["lw1"]), c(o["lb1"]))
+    assert (y - unfused).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("M", [128, 1500, 777, 70000])
 def test_lnqkv_fused(T, gww, M):
     """LayerNorm + q / k / v projection of a residual stream without a pending delta (layer 0) on the fused MLP kernel's

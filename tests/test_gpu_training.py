@@ -305,18 +305,22 @@ def test_lora_step_matches_finite_differences(T, gww):
 
 @pytest.mark.parametrize("projs", [("q_proj", "k_proj", "v_proj"), ("q_proj", "k_proj", "v_proj", "out_proj")],
                          ids=["qkv", "qkvo"])
-@pytest.mark.parametrize("enc_name", ["micro", "tiny"])
+@pytest.mark.parametrize("enc_name", ["micro", "tiny", "small_l2"])
 def test_training_step_matches_finite_differences(T, gww, projs, enc_name):
     """loss.backward() through the HIP encoder (DoRA on q, k, v [, out_proj] of every layer: the two target sets of
     Signal_vs_Noise/src/train.py:230-237 and MLGWSC-1/train.py:695) against central finite differences of the fp64
     oracle forward with the weight norm frozen (detached), for the reduced d = 128 encoder AND for whisper-tiny
     (d = 384, 4 layers: the benchmarked step -- ``k_dora_grads_mfma<384,3>``, A-stationary dX GEMMs, grad-buffer
-    accumulation).  Both forms of the step are checked against the same finite differences: through
+    accumulation) AND for a two-layer encoder of whisper-small's width (d = 768, 12 heads, ffn 3072: BASELINE config 3's
+    kernels -- the generic GEMMs, the per-op forward that saves its activations, the d = 768 form of the DoRA-gradient
+    kernel -- which differ from the fused d = 384 path).  Both forms of the step are checked against the same finite differences: through
     ``last_hidden_state[:, -1]`` and through ``encoder.last_token`` (what models.py calls; its last layer runs on
     the pooled rows only).  Tolerance 3 % (bf16 operands against fp64), measured as described at the directions below."""
     from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
     from gw_whisper_amd.peft import LoraConfig, get_peft_model
-    d, L, H, F = synth.ENCODER_SIZES[enc_name]
+    d, L, H, F = dict(synth.ENCODER_SIZES, small_l2=(768, 2, 12, 3072))[enc_name]
+    if enc_name == "small_l2" and "out_proj" not in projs:
+        pytest.skip("d = 768 is checked once, with the larger target set (MLGWSC-1/train.py:695)")
     cfg = oenc.EncCfg(d, L, H, F)
     sd = synth.encoder_state_dict(d, L, H, F, seed=3)
     mel = olm.log_mel(synth.strain_segments(2, seed=33))
