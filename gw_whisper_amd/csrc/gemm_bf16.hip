@@ -22,6 +22,8 @@
 #include "common.h"
 #include "epilogue.h"
 
+#include <stdlib.h>
+
 namespace gww {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -275,6 +277,122 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v2(const unsigned short* _
   }
 }
 
+// v3: 256 x 256 x 64 tiles for the wide panels of whisper-base / -small (N % 256 == 0).  v2's 256 x 128 tile needs
+// 48 KB of operands per 4.2 MFLOP -- 47 B per clock and CU at the MFMA rate, three quarters of what the L2 can deliver to
+// 256 CUs at once; the square tile needs 64 KB per 8.4 MFLOP, 31 B per clock.  512 threads = 2 x 4 waves of 128 x 64
+// (8 x 4 accumulator tiles of v_mfma_f32_16x16x32_bf16, 24 fragment reads per 64 MFMAs), two 64-KB stages (A | W, the same
+// lane-linear LDS-DMA images and source-side XOR swizzle as v2), the (n, k) iteration space flattened over the block's
+// n-tiles so the ring never drains inside a panel: wait for tile it -> barrier -> 64 MFMAs -> barrier -> request tile
+// it + 2 into the stage just read.  The epilogue's 32 stores per lane sit in front of the next request in the queue and
+// are named in the counted wait (they stay in flight across the next tile).
+constexpr int BM3 = 256, BN3 = 256, BK3 = 64;
+constexpr int A3_BYTES = BM3 * BK3 * 2, W3_BYTES = BN3 * BK3 * 2, STAGE3_BYTES = A3_BYTES + W3_BYTES;
+constexpr int GLDS3 = 8;       // per thread and k-tile: 4 (A) + 4 (W)
+constexpr int STORES3 = 32;    // per thread and output tile
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void k_gemm_bf16_v3(const unsigned short* __restrict__ A, long lda,
+                                                         const unsigned short* __restrict__ W,
+                                                         const float* __restrict__ bias, const float* resid,
+                                                         void* C, long M, int N, int K, int tiles_n, int n_split) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE3_BYTES + 1536 * 4];
+  float* lds_bias = reinterpret_cast<float*>(lds + 2 * STAGE3_BYTES);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* g_ptr;
+
+  const int panel = blockIdx.x / n_split, split = blockIdx.x - panel * n_split;
+  const int nt0 = (int)((long)split * tiles_n / n_split), nt1 = (int)((long)(split + 1) * tiles_n / n_split);
+  const long m0 = (long)panel * BM3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nk = K / BK3;
+  const int total = (nt1 - nt0) * nk;
+
+  for (int i = tid; i < (nt1 - nt0) * BN3; i += 512) lds_bias[i] = bias ? bias[nt0 * BN3 + i] : 0.f;
+
+  const unsigned short* a_src[4];
+  long w_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 8 * (4 * wave + j) + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    long ar = m0 + row;
+    if (ar >= M) ar = M - 1;           // rows past M only feed rows past M
+    a_src[j] = A + ar * lda + chunk * 8;
+    w_off[j] = (long)row * K + chunk * 8;
+  }
+  auto issue = [&](int it) {
+    const int stage = it & 1;
+    const int nn = nt0 + it / nk, k0 = (it % nk) * BK3;
+    unsigned char* sa = lds + stage * STAGE3_BYTES + (4 * wave) * 1024;
+    unsigned char* sw = sa + A3_BYTES;
+    const unsigned short* wb = W + (long)nn * BN3 * K + k0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((g_ptr)(a_src[j] + k0), (lds_ptr)(sa + j * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((g_ptr)(wb + w_off[j]), (lds_ptr)(sw + j * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (total > 0) issue(0);
+  if (total > 1) issue(1);
+  const int frow = lane & 15, fk = lane >> 4;
+  bool stores_pending = false;   // an epilogue's stores sit between tile it and the youngest request
+  for (int it = 0; it < total; ++it) {
+    if (it + 1 < total) {
+      if (stores_pending) wait_vmcnt<GLDS3 + STORES3>();
+      else wait_vmcnt<GLDS3>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    stores_pending = false;
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* As = lds + (it & 1) * STAGE3_BYTES;
+    const unsigned char* Ws = As + A3_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[8], wf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        wf[j] = *reinterpret_cast<const bf16x8*>(Ws + swz_off(wn * 64 + j * 16 + frow, ks * 4 + fk));
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(As + swz_off(wm * 128 + i * 16 + frow, ks * 4 + fk));
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if ((it + 1) % nk == 0) {
+      const int nn = nt0 + it / nk;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const long m = m0 + wm * 128 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
+          const float4 bv = *reinterpret_cast<const float4*>(lds_bias + (nn - nt0) * BN3 + nl);
+          f32x4 v = acc[i][j];
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+          epilogue_store4<EPI, true>(v, m, nn * BN3 + nl, 0x7fffffffffffffffL, N, nullptr, resid, nullptr, C, 0, 0);
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      stores_pending = true;
+    }
+    __builtin_amdgcn_s_barrier();        // every wave has read stage it & 1
+    if (it + 2 < total) issue(it + 2);
+  }
+}
+
 static int pick_n_split(long panels, int tiles_n) {
   // enough workgroups to fill 256 CUs a few times over, but keep the n-loop long
   int s = 1;
@@ -305,6 +423,34 @@ int launch_gemm_bf16(const void* A, long lda, const void* W, const float* bias, 
     valid_rows = rows_per_batch - 2;
   } else if (epi == EPI_RESID) {
     GWW_REQUIRE(resid != nullptr, "gemm_bf16: residual epilogue needs resid");
+  }
+  static const bool use_v3 = !(getenv("GWW_GEMM_V3") && atoi(getenv("GWW_GEMM_V3")) == 0);
+  if (use_v3 && rows_padded_256 && N % BN3 == 0 && N <= 12288 && M >= 4096 &&
+      (epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID)) {
+    // wide panels (whisper-base / -small): 256 x 256 tiles.  A block's bias slice lives in 1536 floats of LDS: at most
+    // six n-tiles per block; enough blocks for a few rounds over the 256 CUs
+    const long panels = cdiv(M, BM3);
+    const int tn3 = N / BN3;
+    int n_split = 1;
+    for (int s2 = 1; s2 <= tn3; ++s2) {
+      if (tn3 % s2) continue;
+      n_split = s2;
+      if (tn3 / s2 <= 6 && panels * s2 >= 768) break;
+    }
+    dim3 grid3((unsigned)(panels * n_split)), block3(512);
+#define GWW_GEMM3_CASE(E)                                                                             \
+  case E:                                                                                             \
+    hipLaunchKernelGGL((k_gemm_bf16_v3<E>), grid3, block3, 0, s, (const unsigned short*)A, lda,       \
+                       (const unsigned short*)W, bias, resid, C, M, N, K, tn3, n_split);              \
+    break;
+    switch (epi) {
+      GWW_GEMM3_CASE(EPI_BIAS) GWW_GEMM3_CASE(EPI_GELU) GWW_GEMM3_CASE(EPI_RESID)
+      default:
+        return fail(GWW_ERR_ARG, "gemm_bf16: unknown epilogue %d", epi);
+    }
+#undef GWW_GEMM3_CASE
+    GWW_LAUNCH_CHECK();
+    return GWW_OK;
   }
   if (rows_padded_256 && N % BN2 == 0 && N <= 6144 && M >= 4096 && epi != EPI_CONV1) {
     // large-M path; the caller has padded A / C / resid to a multiple of 256 rows.
