@@ -285,6 +285,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v2(const unsigned short* _
 // n-tiles so the ring never drains inside a panel: wait for tile it -> barrier -> 64 MFMAs -> barrier -> request tile
 // it + 2 into the stage just read.  The epilogue's 32 stores per lane sit in front of the next request in the queue and
 // are named in the counted wait (they stay in flight across the next tile).
+#ifndef GWW_G3_ABL
+#define GWW_G3_ABL 0   // diagnostic builds only (wrong results): 1 = no epilogue stores, 2 = no LDS-DMA / ring waits, 4 = no fragment reads
+#endif
 constexpr int BM3 = 256, BN3 = 256, BK3 = 64;
 constexpr int A3_BYTES = BM3 * BK3 * 2, W3_BYTES = BN3 * BK3 * 2, STAGE3_BYTES = A3_BYTES + W3_BYTES;
 constexpr int GLDS3 = 8;       // per thread and k-tile: 4 (A) + 4 (W)
@@ -300,7 +303,18 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v3(const unsigned short* _
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* g_ptr;
 
-  const int panel = blockIdx.x / n_split, split = blockIdx.x - panel * n_split;
+  // Work item = (column split, row panel), split-major; the blocks of one XCD (blockIdx % 8: they share an L2) take a
+  // CONTIGUOUS range of items, i.e. they walk the panels of one column split together: that split's W slice (<= 1.5 MB,
+  // launch_gemm_bf16) stays in the XCD's L2 while the A panels stream past it once.  With the panel-major order of v2
+  // every XCD touched every column of W (4.7 MB for whisper-small's fc1, more than an L2 holds) and the weights came
+  // from beyond the L2 over and over: ~700 TFLOP/s whatever the tile.
+  const int panels = (int)(gridDim.x / n_split);
+  int item;
+  {
+    const int nb = (int)gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    item = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  }
+  const int split = item / panels, panel = item - split * panels;
   const int nt0 = (int)((long)split * tiles_n / n_split), nt1 = (int)((long)(split + 1) * tiles_n / n_split);
   const long m0 = (long)panel * BM3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -322,6 +336,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v3(const unsigned short* _
     w_off[j] = (long)row * K + chunk * 8;
   }
   auto issue = [&](int it) {
+    if (GWW_G3_ABL & 2) return;
     const int stage = it & 1;
     const int nn = nt0 + it / nk, k0 = (it % nk) * BK3;
     unsigned char* sa = lds + stage * STAGE3_BYTES + (4 * wave) * 1024;
@@ -346,8 +361,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v3(const unsigned short* _
   const int frow = lane & 15, fk = lane >> 4;
   bool stores_pending = false;   // an epilogue's stores sit between tile it and the youngest request
   for (int it = 0; it < total; ++it) {
-    if (it + 1 < total) {
-      if (stores_pending) wait_vmcnt<GLDS3 + STORES3>();
+    if (GWW_G3_ABL & 2) {
+    } else if (it + 1 < total) {
+      if (stores_pending && !(GWW_G3_ABL & 1)) wait_vmcnt<GLDS3 + STORES3>();
       else wait_vmcnt<GLDS3>();
     } else {
       wait_vmcnt<0>();
@@ -361,10 +377,10 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v3(const unsigned short* _
       bf16x8 af[8], wf[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        wf[j] = *reinterpret_cast<const bf16x8*>(Ws + swz_off(wn * 64 + j * 16 + frow, ks * 4 + fk));
+        wf[j] = *reinterpret_cast<const bf16x8*>(Ws + ((GWW_G3_ABL & 4) ? 0 : swz_off(wn * 64 + j * 16 + frow, ks * 4 + fk)));
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(As + swz_off(wm * 128 + i * 16 + frow, ks * 4 + fk));
+        af[i] = *reinterpret_cast<const bf16x8*>(As + ((GWW_G3_ABL & 4) ? 0 : swz_off(wm * 128 + i * 16 + frow, ks * 4 + fk)));
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -382,7 +398,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v3(const unsigned short* _
           const float4 bv = *reinterpret_cast<const float4*>(lds_bias + (nn - nt0) * BN3 + nl);
           f32x4 v = acc[i][j];
           v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-          epilogue_store4<EPI, true>(v, m, nn * BN3 + nl, 0x7fffffffffffffffL, N, nullptr, resid, nullptr, C, 0, 0);
+          if (GWW_G3_ABL & 1) asm volatile("" :: "v"(v));
+          else epilogue_store4<EPI, true>(v, m, nn * BN3 + nl, 0x7fffffffffffffffL, N, nullptr, resid, nullptr, C, 0, 0);
           acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
@@ -431,12 +448,14 @@ int launch_gemm_bf16(const void* A, long lda, const void* W, const float* bias, 
     // six n-tiles per block; enough blocks for a few rounds over the 256 CUs
     const long panels = cdiv(M, BM3);
     const int tn3 = N / BN3;
-    int n_split = 1;
-    for (int s2 = 1; s2 <= tn3; ++s2) {
-      if (tn3 % s2) continue;
-      n_split = s2;
-      if (tn3 / s2 <= 6 && panels * s2 >= 768) break;
-    }
+    // column splits: a split's W slice should sit in one XCD's 4-MB L2 beside the streaming A panels (<= 1.5 MB), and its
+    // bias slice in 1536 floats of LDS (<= 6 n-tiles)
+    long fit = (3L << 19) / ((long)BN3 * K * 2);
+    if (fit < 1) fit = 1;
+    if (fit > 6) fit = 6;
+    int n_split = tn3;
+    for (int s2 = 1; s2 <= tn3; ++s2)
+      if (tn3 % s2 == 0 && tn3 / s2 <= fit && (panels * s2 >= 768 || s2 == tn3)) { n_split = s2; break; }
     dim3 grid3((unsigned)(panels * n_split)), block3(512);
 #define GWW_GEMM3_CASE(E)                                                                             \
   case E:                                                                                             \

@@ -94,11 +94,21 @@ constexpr int MF_OFF_B2 = MF_OFF_U + MF_FMAX * 4;
 constexpr int MF_OFF_BO = MF_OFF_B2 + MF_D * 4;     // out_proj bias (OP mode)
 constexpr int MF_OFF_QCB = MF_OFF_BO + MF_D * 4;    // folded bias of the appended q / k / v panel (staged at kernel start)
 constexpr int MF_OFF_SLICE = MF_OFF_QCB + MF_FMAX * 4;
-constexpr int MF_LDS = MF_OFF_SLICE + MF_WAVES * MF_SLICE_BYTES;
+constexpr int MF_LDS = MF_OFF_SLICE + 2 * MF_WAVES * MF_SLICE_BYTES;   // two slices per wave: the seams alternate (below)
 static_assert(MF_LDS <= 160 * 1024, "LDS budget");
 
 template <int N>
 using MF_FL = std::integral_constant<int, N>;   // flat index of a tile in the unrolled stream (its ring stage, mod 4)
+
+// sum over the 8 lanes of a row group (lane & 7): three DPP adds -- quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
+// (lane i <-> 7 - i of its 8: the other quad).  __shfl_xor lowers to ds_bpermute_b32 here: an LDS round trip per step
+// in a dependent chain, and a lane-index register per step (three of the kernel's spills).
+__device__ __forceinline__ float mf_sum8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  return v;
+}
 
 template <int N>
 __device__ __forceinline__ void mf_wait_vmcnt() {
@@ -192,6 +202,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   const int r = lane & 31, hh = lane >> 5;
   const long m_base = (long)blockIdx.x * MF_BM + wave * 32;
   unsigned char* slice = lds + MF_OFF_SLICE + wave * MF_SLICE_BYTES;
+  unsigned char* const slice0 = slice;
   const int crow = lane >> 3, cchunk = lane & 7;
 
   // ---- ring: the weights arrive pre-tiled (gww_mlp_pack_bf16): tile (c, idx) is 16 contiguous KiB that
@@ -359,9 +370,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
             }
             if (S == 0 && h2 == 0) {
               float t = (v[0] + v[1]) + (v[2] + v[3]);
-              t += __shfl_xor(t, 1, 64);
-              t += __shfl_xor(t, 2, 64);
-              t += __shfl_xor(t, 4, 64);
+              t = mf_sum8(t);
               cshift[i] = t * (1.0f / 32.0f);
             }
             v[0] -= cshift[i]; v[1] -= cshift[i]; v[2] -= cshift[i]; v[3] -= cshift[i];
@@ -383,9 +392,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float a = s1[i], b = s2[i];
-      a += __shfl_xor(a, 1, 64); b += __shfl_xor(b, 1, 64);
-      a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64);
-      a += __shfl_xor(a, 4, 64); b += __shfl_xor(b, 4, 64);
+      a = mf_sum8(a); b = mf_sum8(b);
       const float mean = a * (1.0f / MF_D);
       const float var = fmaxf(b * (1.0f / MF_D) - mean * mean, 0.f);
       if (cchunk == 0) {
@@ -784,6 +791,9 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       };
 #pragma unroll
       for (int np = 0; np < MF_KT; ++np) {
+        // the chunks alternate between two wave-private slices: chunk np + 1's transposed output tile can be written while
+        // chunk np's operand fragments are still being read back (one slice serialised the six chunks on their LDS round trips)
+        unsigned char* const slice = slice0 + (np & 1) * (MF_WAVES * MF_SLICE_BYTES);
         if (np == 0) {
           request(0);
           after_request();   // work whose own memory latency runs beside the first batch's
@@ -823,9 +833,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
             xn4[np % 3][h2][i] = v;      // x_next, stored once the batch is consumed
             if (np == 0 && h2 == 0) {
               float t = (v[0] + v[1]) + (v[2] + v[3]);
-              t += __shfl_xor(t, 1, 64);
-              t += __shfl_xor(t, 2, 64);
-              t += __shfl_xor(t, 4, 64);
+              t = mf_sum8(t);
               cshift[i] = t * (1.0f / 32.0f);
             }
             v[0] -= cshift[i]; v[1] -= cshift[i]; v[2] -= cshift[i]; v[3] -= cshift[i];
@@ -843,13 +851,11 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         if (np == 2) request(3);   // batch 0 consumed: batch 1 is requested first, chunk 2's stores go behind it
         store_chunk(np);
       }
-      float* stat = reinterpret_cast<float*>(slice);
+      float* stat = reinterpret_cast<float*>(slice0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float a = s1[i], b = s2[i];
-        a += __shfl_xor(a, 1, 64); b += __shfl_xor(b, 1, 64);
-        a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64);
-        a += __shfl_xor(a, 4, 64); b += __shfl_xor(b, 4, 64);
+        a = mf_sum8(a); b = mf_sum8(b);
         const float mean = a * (1.0f / MF_D);
         const float var = fmaxf(b * (1.0f / MF_D) - mean * mean, 0.f);
         if (cchunk == 0) {
@@ -1026,9 +1032,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           v[3] += bf2f((unsigned short)(dv[1] >> 16));
           if (np == 0 && h2 == 0) {
             float t = (v[0] + v[1]) + (v[2] + v[3]);
-            t += __shfl_xor(t, 1, 64);
-            t += __shfl_xor(t, 2, 64);
-            t += __shfl_xor(t, 4, 64);
+            t = mf_sum8(t);
             cshift[i] = t * (1.0f / 32.0f);
           }
           v[0] -= cshift[i]; v[1] -= cshift[i]; v[2] -= cshift[i]; v[3] -= cshift[i];
@@ -1041,9 +1045,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float a = s1[i], b = s2[i];
-      a += __shfl_xor(a, 1, 64); b += __shfl_xor(b, 1, 64);
-      a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64);
-      a += __shfl_xor(a, 4, 64); b += __shfl_xor(b, 4, 64);
+      a = mf_sum8(a); b = mf_sum8(b);
       mean_s[i] = a * (1.0f / MF_D);
       rstd[i] = rsqrtf(fmaxf(b * (1.0f / MF_D) - mean_s[i] * mean_s[i], 0.f) + 1e-5f);
     }
