@@ -37,7 +37,7 @@ import torch  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # collected by tools/pmc_traffic.py (separate rocprofv3 --pmc passes)
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # collected by tools/pmc_traffic.py (separate rocprofv3 --pmc passes)
 T_TOK, T_IN, DH = 1500, 3000, 64
 
 

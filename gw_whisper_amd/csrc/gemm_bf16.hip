@@ -277,37 +277,45 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v2(const unsigned short* _
   }
 }
 
-// v3: 256 x 256 x 64 tiles for the wide panels of whisper-base / -small (N % 256 == 0).  v2's 256 x 128 tile needs
-// 48 KB of operands per 4.2 MFLOP -- 47 B per clock and CU at the MFMA rate, three quarters of what the L2 can deliver to
-// 256 CUs at once; the square tile needs 64 KB per 8.4 MFLOP, 31 B per clock.  512 threads = 2 x 4 waves of 128 x 64
-// (8 x 4 accumulator tiles of v_mfma_f32_16x16x32_bf16, 24 fragment reads per 64 MFMAs), two 64-KB stages (A | W, the same
-// lane-linear LDS-DMA images and source-side XOR swizzle as v2), the (n, k) iteration space flattened over the block's
-// n-tiles so the ring never drains inside a panel: wait for tile it -> barrier -> 64 MFMAs -> barrier -> request tile
-// it + 2 into the stage just read.  The epilogue's 32 stores per lane sit in front of the next request in the queue and
-// are named in the counted wait (they stay in flight across the next tile).
+// v3: 256 x 256 tiles for the wide panels of whisper-base / -small (N % 256 == 0).  v2's 256 x 128 tile needs 48 KB of
+// operands per 4.2 MFLOP -- 47 B per clock and CU at the MFMA rate; the square tile needs 64 KB per 8.4 MFLOP.
+// 512 threads = 2 x 4 waves of 128 x 64 (8 x 4 accumulator tiles of v_mfma_f32_16x16x32_bf16).  What the ablation builds
+// (GWW_G3_ABL, tools/gemm_exp.py) showed on the first form of this kernel (two 64-KB stages, BK = 64: 640-700 TFLOP/s
+// where MFMAs + barriers alone run 1 500-1 870): the eight LDS-DMA pieces per wave and k-tile cost ~60 issue cycles each
+// and had to go out in one burst behind the tile's second barrier (-25 %), the 32 eight-byte stores per lane of the
+// epilogue another 25-30 %.  Hence:
+//   * BK = 32, FOUR 32-KB stages, three k-tiles in flight: the four DMA pieces of tile it + 3 are issued one per eight
+//     MFMAs inside tile it (their stage was read in tile it - 1: ONE barrier per k-tile), counted vmcnt;
+//   * LDS rows are 64 B: the 16-byte chunk p of row R sits at p ^ 2 ((R >> 3) & 1) -- conflict-free for the lane
+//     groups of ds_read_b128 (rows R, R + 4, R + 8, R + 12 of a 16-row fragment share a bank row);
+//   * bf16 epilogue: v_permlane16_swap pairs neighbouring 16-column tiles so that every lane stores 16 bytes (64
+//     contiguous bytes per row and instruction) -- 16 stores per lane instead of 32 of eight bytes.
+// Work item = (column split, row panel), split-major, contiguous per XCD (blockIdx % 8): the blocks of an XCD walk the
+// panels of one column split together, whose W slice (<= 1.5 MB) stays in that L2.
 #ifndef GWW_G3_ABL
 #define GWW_G3_ABL 0   // diagnostic builds only (wrong results): 1 = no epilogue stores, 2 = no LDS-DMA / ring waits, 4 = no fragment reads
 #endif
-constexpr int BM3 = 256, BN3 = 256, BK3 = 64;
-constexpr int A3_BYTES = BM3 * BK3 * 2, W3_BYTES = BN3 * BK3 * 2, STAGE3_BYTES = A3_BYTES + W3_BYTES;
-constexpr int GLDS3 = 8;       // per thread and k-tile: 4 (A) + 4 (W)
-constexpr int STORES3 = 32;    // per thread and output tile
+constexpr int BM3 = 256, BN3 = 256, BK3 = 32, NST3 = 4;
+constexpr int A3_BYTES = BM3 * BK3 * 2, W3_BYTES = BN3 * BK3 * 2, STAGE3_BYTES = A3_BYTES + W3_BYTES;   // 16 + 16 KB
+constexpr int GLDS3 = 4;       // per thread and k-tile: 2 (A) + 2 (W)
+
+__device__ __forceinline__ int swz3(int row, int chunk) {   // byte offset inside a [256][32] bf16 tile (64-byte rows)
+  return row * 64 + ((chunk ^ (((row >> 3) & 1) << 1)) << 4);
+}
 
 template <int EPI>
 __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v3(const unsigned short* __restrict__ A, long lda,
                                                          const unsigned short* __restrict__ W,
                                                          const float* __restrict__ bias, const float* resid,
                                                          void* C, long M, int N, int K, int tiles_n, int n_split) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE3_BYTES + 1536 * 4];
-  float* lds_bias = reinterpret_cast<float*>(lds + 2 * STAGE3_BYTES);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NST3 * STAGE3_BYTES + 1536 * 4];
+  float* lds_bias = reinterpret_cast<float*>(lds + NST3 * STAGE3_BYTES);
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* g_ptr;
+  constexpr bool BF16OUT = EPI != EPI_RESID;
+  unsigned short* __restrict__ const Cb = reinterpret_cast<unsigned short*>(C);   // (bf16 output never aliases an operand)
+  constexpr int STORES3 = BF16OUT ? 16 : 32;   // per thread and output tile
 
-  // Work item = (column split, row panel), split-major; the blocks of one XCD (blockIdx % 8: they share an L2) take a
-  // CONTIGUOUS range of items, i.e. they walk the panels of one column split together: that split's W slice (<= 1.5 MB,
-  // launch_gemm_bf16) stays in the XCD's L2 while the A panels stream past it once.  With the panel-major order of v2
-  // every XCD touched every column of W (4.7 MB for whisper-small's fc1, more than an L2 holds) and the weights came
-  // from beyond the L2 over and over: ~700 TFLOP/s whatever the tile.
   const int panels = (int)(gridDim.x / n_split);
   int item;
   {
@@ -324,30 +332,30 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v3(const unsigned short* _
 
   for (int i = tid; i < (nt1 - nt0) * BN3; i += 512) lds_bias[i] = bias ? bias[nt0 * BN3 + i] : 0.f;
 
-  const unsigned short* a_src[4];
-  long w_off[4];
+  // LDS-DMA pieces: 1 KiB = 16 rows x 64 B; lane l lands at (row l >> 2, position l & 3), which holds chunk
+  // (l & 3) ^ 2 ((row >> 3) & 1) of the row
+  const unsigned short* a_src[2];
+  long w_off[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = 8 * (4 * wave + j) + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+  for (int j = 0; j < 2; ++j) {
+    const int row = 16 * (2 * wave + j) + (lane >> 2);
+    const int chunk = (lane & 3) ^ (((row >> 3) & 1) << 1);
     long ar = m0 + row;
     if (ar >= M) ar = M - 1;           // rows past M only feed rows past M
     a_src[j] = A + ar * lda + chunk * 8;
     w_off[j] = (long)row * K + chunk * 8;
   }
-  auto issue = [&](int it) {
+  auto issue_piece = [&](int it, int j) {   // piece j (0, 1: A; 2, 3: W) of k-tile it
     if (GWW_G3_ABL & 2) return;
-    const int stage = it & 1;
+    const int stage = it & (NST3 - 1);
     const int nn = nt0 + it / nk, k0 = (it % nk) * BK3;
-    unsigned char* sa = lds + stage * STAGE3_BYTES + (4 * wave) * 1024;
-    unsigned char* sw = sa + A3_BYTES;
-    const unsigned short* wb = W + (long)nn * BN3 * K + k0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
+    unsigned char* sa = lds + stage * STAGE3_BYTES + (2 * wave) * 1024;
+    if (j < 2) {
       __builtin_amdgcn_global_load_lds((g_ptr)(a_src[j] + k0), (lds_ptr)(sa + j * 1024), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((g_ptr)(wb + w_off[j]), (lds_ptr)(sw + j * 1024), 16, 0, 0);
+    } else {
+      const unsigned short* wb = W + (long)nn * BN3 * K + k0;
+      __builtin_amdgcn_global_load_lds((g_ptr)(wb + w_off[j - 2]), (lds_ptr)(sa + A3_BYTES + (j - 2) * 1024), 16, 0, 0);
+    }
   };
 
   f32x4 acc[8][4];
@@ -356,57 +364,93 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v3(const unsigned short* _
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (total > 0) issue(0);
-  if (total > 1) issue(1);
+#pragma unroll
+  for (int p = 0; p < NST3 - 1; ++p)
+    if (p < total)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) issue_piece(p, j);
   const int frow = lane & 15, fk = lane >> 4;
-  bool stores_pending = false;   // an epilogue's stores sit between tile it and the youngest request
+  int stores_age = 0;   // > 0: an epilogue's stores may still sit in the queue behind the tile being waited for
   for (int it = 0; it < total; ++it) {
+    // tile it was requested three tiles ago; younger: the pieces of tiles it + 1, it + 2 and the stores of an epilogue
+    // in one of the last two tiles
     if (GWW_G3_ABL & 2) {
-    } else if (it + 1 < total) {
-      if (stores_pending && !(GWW_G3_ABL & 1)) wait_vmcnt<GLDS3 + STORES3>();
-      else wait_vmcnt<GLDS3>();
+    } else if (it + 2 < total) {
+      if (stores_age > 0 && !(GWW_G3_ABL & 1)) wait_vmcnt<2 * GLDS3 + STORES3>();
+      else wait_vmcnt<2 * GLDS3>();
     } else {
       wait_vmcnt<0>();
     }
-    stores_pending = false;
+    if (stores_age > 0) --stores_age;
     __builtin_amdgcn_s_barrier();
-    const unsigned char* As = lds + (it & 1) * STAGE3_BYTES;
+    const unsigned char* As = lds + (it & (NST3 - 1)) * STAGE3_BYTES;
     const unsigned char* Ws = As + A3_BYTES;
+    bf16x8 af[8], wf[4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[8], wf[4];
+    for (int j = 0; j < 4; ++j)
+      wf[j] = *reinterpret_cast<const bf16x8*>(Ws + ((GWW_G3_ABL & 4) ? 0 : swz3(wn * 64 + j * 16 + frow, fk)));
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      af[i] = *reinterpret_cast<const bf16x8*>(As + ((GWW_G3_ABL & 4) ? 0 : swz3(wm * 128 + i * 16 + frow, fk)));
+    const bool more = it + NST3 - 1 < total;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (more && (i & 1) == 0) issue_piece(it + NST3 - 1, i >> 1);   // one DMA piece per eight MFMAs
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        wf[j] = *reinterpret_cast<const bf16x8*>(Ws + ((GWW_G3_ABL & 4) ? 0 : swz_off(wn * 64 + j * 16 + frow, ks * 4 + fk)));
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(As + ((GWW_G3_ABL & 4) ? 0 : swz_off(wm * 128 + i * 16 + frow, ks * 4 + fk)));
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
     if ((it + 1) % nk == 0) {
       const int nn = nt0 + it / nk;
+      // the bias of this lane's four column groups: asm reads -- hipcc cannot tell these LDS reads from the LDS-DMA
+      // destinations in the same array and would drain the whole ring (vmcnt(0)) in front of them
+      f32x4 bvj[4];
+      {
+        const unsigned ba = (unsigned)(unsigned long long)(lds_ptr)(lds_bias + (nn - nt0) * BN3 + wn * 64 + (lane >> 4) * 4);
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+                     "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(bvj[0]), "=&v"(bvj[1]), "=&v"(bvj[2]), "=&v"(bvj[3]) : "v"(ba));
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const long m = m0 + wm * 128 + i * 16 + (lane & 15);
+        if constexpr (BF16OUT) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
-          const float4 bv = *reinterpret_cast<const float4*>(lds_bias + (nn - nt0) * BN3 + nl);
-          f32x4 v = acc[i][j];
-          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-          if (GWW_G3_ABL & 1) asm volatile("" :: "v"(v));
-          else epilogue_store4<EPI, true>(v, m, nn * BN3 + nl, 0x7fffffffffffffffL, N, nullptr, resid, nullptr, C, 0, 0);
-          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int jp = 0; jp < 4; jp += 2) {
+            unsigned pk[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const f32x4 bv = bvj[jp + t];
+              float v0 = acc[i][jp + t][0] + bv[0], v1 = acc[i][jp + t][1] + bv[1], v2 = acc[i][jp + t][2] + bv[2],
+                    v3 = acc[i][jp + t][3] + bv[3];
+              if constexpr (EPI == EPI_GELU) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
+              pk[t][0] = pack2bf(v0, v1);
+              pk[t][1] = pack2bf(v2, v3);
+              acc[i][jp + t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            // lanes of 16-lane row g hold columns 4 g .. 4 g + 3 of each tile; after the swaps: g = 0 / 2 hold eight
+            // columns of tile jp (their own four + the next row's), g = 1 / 3 eight columns of tile jp + 1
+            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+            const int g = lane >> 4;
+            const int col = nn * BN3 + wn * 64 + (jp + (g & 1)) * 16 + 8 * (g >> 1);
+            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+            if (GWW_G3_ABL & 1) asm volatile("" :: "v"(o));
+            else *reinterpret_cast<u32x4*>(Cb + m * N + col) = o;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
+            f32x4 v = acc[i][j] + bvj[j];
+            if (GWW_G3_ABL & 1) asm volatile("" :: "v"(v));
+            else epilogue_store4<EPI, true>(v, m, nn * BN3 + nl, 0x7fffffffffffffffL, N, nullptr, resid, nullptr, C, 0, 0);
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
       }
-      stores_pending = true;
+      stores_age = 3;   // the stores sit behind the pieces of tile it + 3: tiles it + 1 .. it + 3 may overtake them
     }
-    __builtin_amdgcn_s_barrier();        // every wave has read stage it & 1
-    if (it + 2 < total) issue(it + 2);
   }
 }
 
