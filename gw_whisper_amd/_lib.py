@@ -123,6 +123,8 @@ SIGNATURES = {
     "gww_welch_power_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "gww_column_median_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
     "gww_fir_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p]),
+    "gww_cluster_triggers_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_double, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_void_p]),
     "gww_gemm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gww_attention_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -513,9 +513,11 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   GWW_HIP(hipMemsetAsync(c1, 0, (size_t)d * es, s));   // zero row 0 of batch 0 (token -1)
   // A-stationary kernels (A panel in registers, fused residual-add + LayerNorm prologue) for K = d <= 512
   // GWW_GENERIC_PATH (debug aid): bit 0 = generic layer GEMMs, bit 1 = generic conv1, bit 2 = generic conv2, bit 3 = unfused MLP,
-  // bit 4 = stand-alone QKV, bit 5 = no pooled last layer, bit 6 = layer 0's LN1 + QKV by the LN-fused A-stationary GEMM, bit 7 = stand-alone out_proj
+  // bit 4 = stand-alone QKV, bit 5 = no pooled last layer, bit 6 = layer 0's LN1 + QKV by the LN-fused A-stationary GEMM, bit 7 = stand-alone out_proj, bit 8 = stand-alone final LayerNorm, bit 9 = A-stationary layer GEMMs at d = 512
   static const int generic_mask = getenv("GWW_GENERIC_PATH") ? atoi(getenv("GWW_GENERIC_PATH")) : 0;
-  const bool astat = bf && (d == 384 || d == 512) && F % 128 == 0 && !(generic_mask & 1);
+  // d = 512 (whisper-base): since round 3 the LayerNorm kernel + the 256 x 256 GEMM (k_gemm_bf16_v3) beat the LN-fused
+  // A-stationary layer GEMMs there (8.78 against 9.33 ms per 64 segments; bit 9 of the mask brings them back)
+  const bool astat = bf && (d == 384 || (d == 512 && (generic_mask & 512))) && F % 128 == 0 && !(generic_mask & 1);
   const bool mlp_fused = astat && d == 384 && F <= 1536 && !(generic_mask & 8);   // bit 3 = separate fc1 / fc2 kernels
   const bool fuse_qkv = mlp_fused && !(generic_mask & 16);                          // bit 4 = stand-alone LN1 + QKV kernels
   bool qkv_done = false;

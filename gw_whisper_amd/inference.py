@@ -9,6 +9,8 @@ step), the threshold is applied on the device and triggers leave the GPU in one 
     DeviceSegmentSlicer      <->  SegmentSlicer / TorchSegmentSlicer in ``white=True`` mode (:173-296)
     evaluate_slices          <->  evaluate_slices (:454-489), same return value
     get_clusters             <->  get_clusters (:140-166), host side, unchanged arithmetic
+    cluster_triggers_device       the same clustering on the device (``gww_cluster_triggers_f64``): scores are thresholded and
+                                  clustered where they were computed, one small copy of the clusters leaves the GPU
     GWWhisperClassifier      <->  GWWhisperClassifier (:353-392 / train.py:170-214): adapter -> encoder per detector
                                   -> last token -> MLP (+ Softmax)
     RegBCELoss               <->  train.py:358-370
@@ -185,13 +187,14 @@ class DeviceSegmentSlicer:
 
 def evaluate_slices(slicer: DeviceSegmentSlicer, network: nn.Module, device: str = "cuda",
                     trigger_threshold: float = 0.2, verbose: bool = False,
-                    batch_size: int = 256, window_range: Optional[Tuple[int, int]] = None
-                    ) -> Tuple[List[List[float]], List[np.ndarray]]:
+                    batch_size: int = 256, window_range: Optional[Tuple[int, int]] = None,
+                    cluster_threshold: Optional[float] = None):
     """Reference ``evaluate_slices`` (``inference.py:454-489``): run ``network`` over all windows in batches of 256,
     keep ``outputs[:, 0]`` as the signal score, return ``([[time, score], ...] above threshold, [scores per batch])``.
     Scores and times stay on the device; the threshold is one comparison + ``nonzero`` and everything leaves the
     GPU in two copies per segment instead of one ``.item()`` per window.  ``window_range``: evaluate only windows
-    ``[w0, w1)`` (a rank's batch-aligned shard)."""
+    ``[w0, w1)`` (a rank's batch-aligned shard).  ``cluster_threshold``: also cluster the triggers of these windows on the
+    device (``cluster_triggers_device``) and return ``(triggers, scores per batch, (times, values, variances))``."""
     w0, w1 = (0, len(slicer)) if window_range is None else window_range      # one rank's shard (shard_windows)
     n = w1 - w0
     scores = torch.empty((n,), dtype=torch.float32, device=slicer.dss.device)
@@ -204,9 +207,38 @@ def evaluate_slices(slicer: DeviceSegmentSlicer, network: nn.Module, device: str
         times = slicer.times(w0, w1)
         trig = torch.stack((times[keep], scores[keep].to(torch.float64)), dim=1).cpu().numpy()
         all_scores = scores.cpu().numpy()
+        clusters = None if cluster_threshold is None else cluster_triggers_device(times, scores, trigger_threshold,
+                                                                                  cluster_threshold)
     new_triggers = [[float(t), float(s)] for t, s in trig]
     all_vals = [all_scores[i0:min(n, i0 + batch_size)] for i0 in range(0, n, batch_size)]
-    return new_triggers, all_vals
+    return (new_triggers, all_vals) if cluster_threshold is None else (new_triggers, all_vals, clusters)
+
+
+def cluster_triggers_device(times: torch.Tensor, scores: torch.Tensor, trigger_threshold: float = 0.2,
+                            cluster_threshold: float = 0.35) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """``get_clusters`` of ONE trigger list (reference ``inference.py:140-166``; the list being the windows of a segment
+    whose score exceeds ``trigger_threshold``, ``:484-487``) on the device: ``times`` fp64 [n] (the reference's stamps,
+    ``DeviceSegmentSlicer.times``), ``scores`` fp32 [n], both on the GPU.  Returns ``(times, values, time variances)``
+    exactly as ``get_clusters`` does -- the per-window scores are never copied to the host for it."""
+    import ctypes as C
+    from ._lib import check, lib
+    if not (times.is_cuda and scores.is_cuda):
+        raise _lib.GwwError("cluster_triggers_device needs GPU tensors")
+    times = times.to(torch.float64).contiguous()
+    scores = scores.to(torch.float32).contiguous()
+    n = scores.numel()
+    cap = max(1, n)                                       # a cluster holds at least one window
+    out_t = torch.empty((cap,), dtype=torch.float64, device=scores.device)
+    out_v = torch.empty((cap,), dtype=torch.float32, device=scores.device)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=scores.device)
+    with torch.cuda.device(scores.device):
+        check(lib().gww_cluster_triggers_f64(times.data_ptr(), scores.data_ptr(), n, float(trigger_threshold),
+                                             float(cluster_threshold), out_t.data_ptr(), out_v.data_ptr(), cnt.data_ptr(), cap,
+                                             torch.cuda.current_stream().cuda_stream), "gww_cluster_triggers_f64")
+    k = int(cnt.item())
+    t = out_t[:k].cpu().numpy()
+    v = out_v[:k].cpu().numpy().astype(np.float64)     # the reference's values are python floats of the fp32 scores
+    return t, v, np.full((k,), 0.2)
 
 
 def get_clusters(triggers: Dict[str, List[List[float]]],

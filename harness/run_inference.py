@@ -155,7 +155,7 @@ def get_triggers(args, device, rank, world):
         segs = {"synthetic": (rng.standard_normal((len(DETECTORS), n)).astype(np.float32), 1.0e9, 1.0 / 2048)}
     else:
         segs = read_segments(args.inputfile)
-    triggers, all_vals = {}, []
+    triggers, all_vals, clusters = {}, [], {}
     for key in sorted(segs, key=lambda k: segs[k][0].shape[1], reverse=True):
         strain, start, dt = segs[key]
         # --white: the file already holds whitened strain; otherwise every segment is whitened on the device first
@@ -164,17 +164,30 @@ def get_triggers(args, device, rank, world):
                                          device=device, white=args.white)
         w0, w1 = inf.shard_windows(len(slicer), rank, world, args.batch_size)
         logging.info("rank %d: segment %s, windows [%d, %d) of %d", rank, key, w0, w1, len(slicer))
-        trig, vals = inf.evaluate_slices(slicer, network, trigger_threshold=args.trigger_threshold,
-                                         batch_size=args.batch_size, window_range=(w0, w1))
-        if world > 1:
+        if world == 1:
+            # one GPU holds every score of the segment: threshold AND cluster on the device (gww_cluster_triggers_f64)
+            trig, vals, clusters[key] = inf.evaluate_slices(slicer, network, trigger_threshold=args.trigger_threshold,
+                                                            batch_size=args.batch_size, window_range=(w0, w1),
+                                                            cluster_threshold=args.cluster_threshold)
+        else:
+            import torch
             import torch.distributed as dist
+            trig, vals = inf.evaluate_slices(slicer, network, trigger_threshold=args.trigger_threshold,
+                                             batch_size=args.batch_size, window_range=(w0, w1))
             parts = [None] * world
             dist.all_gather_object(parts, (trig, vals))
             trig = [x for p in parts for x in p[0]]           # shards are contiguous and in rank order
             vals = [v for p in parts for v in p[1]]
+            if rank == 0:                                     # the gathered scores go back to rank 0's GPU to be clustered
+                full = torch.from_numpy(np.concatenate(vals).astype(np.float32)).to(device) if vals else torch.empty(0, device=device)
+                clusters[key] = inf.cluster_triggers_device(slicer.times(0, len(slicer)), full, args.trigger_threshold,
+                                                            args.cluster_threshold)
         triggers[key] = trig
         all_vals.extend(vals)
-    return dict(sorted(triggers.items(), key=lambda x: x[0])), all_vals
+    keys = sorted(triggers)
+    clustered = tuple(np.concatenate([clusters[k][j] for k in keys]) if keys and all(k in clusters for k in keys) else None
+                      for j in range(3))
+    return dict(sorted(triggers.items(), key=lambda x: x[0])), all_vals, clustered
 
 
 def main(argv=None) -> int:
@@ -197,12 +210,14 @@ def main(argv=None) -> int:
         dist.init_process_group("nccl", device_id=device)
 
     from gw_whisper_amd import inference as inf
-    triggers, all_vals = get_triggers(args, device, rank, world)
+    triggers, all_vals, clustered = get_triggers(args, device, rank, world)
     if rank == 0:
         logging.info("Total slices above threshold %.3f: %d", args.trigger_threshold, sum(len(v) for v in triggers.values()))
         if args.debug_triggers_file is not None:
             write_result(args.debug_triggers_file, {k: np.array(v, dtype=np.float32) for k, v in triggers.items()})
-        time_arr, stat_arr, var_arr = inf.get_clusters(triggers, args.cluster_threshold)
+        # clusters come from the device kernel (per segment, in key order: what get_clusters' loop over the dict does); the
+        # host restatement of the reference stays as the cross-check
+        time_arr, stat_arr, var_arr = clustered if clustered[0] is not None else inf.get_clusters(triggers, args.cluster_threshold)
         flat = np.concatenate(all_vals).astype("float32") if len(all_vals) else np.array([], dtype="float32")
         write_result(args.outputfile, {"time": time_arr, "stat": stat_arr, "var": var_arr, "all_vals": flat})
         print(f"Total execution time: {t.time() - start:.2f} seconds")

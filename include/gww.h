@@ -324,6 +324,14 @@ int gww_welch_power_f32(const float* spec, long ld, long n_seg, int n_bins, floa
 int gww_column_median_f32(const float* power, long n_seg, int n_bins, float* median, void* stream);
 int gww_fir_f32(const float* xp, long xp_stride, const float* g, int taps4, int D, float* out, long out_stride,
                 long n_out, void* stream);
+/* Trigger clustering on the device (MLGWSC-1/inference.py:140-166 `get_clusters` behind :484-487): windows whose score
+ * exceeds trigger_threshold, in time order, join the running cluster unless they lie more than cluster_threshold seconds
+ * behind the previous trigger; per cluster the time and value of its first maximum.  times fp64 [n] (the reference's
+ * stamps), scores fp32 [n]; out_times fp64 / out_vals fp32 [max_clusters], *out_count = clusters found (may exceed
+ * max_clusters: only the first max_clusters are stored).  One launch per trigger list (segment). */
+int gww_cluster_triggers_f64(const double* times, const float* scores, long n, float trigger_threshold,
+                             double cluster_threshold, double* out_times, float* out_vals, int* out_count,
+                             int max_clusters, void* stream);
 int gww_gemm_f32(const float* A, const float* W, const float* bias, const float* resid, float* C,
                  long M, int N, int K, int epilogue, void* stream);
 /* softmax(q k^T) v per head, q pre-scaled; qkv [B,T,3*d] (q|k|v), ctx [B,T,d]; head_dim 64 */

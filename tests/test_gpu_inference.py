@@ -316,3 +316,39 @@ def test_config4_q_front_end_feeds_the_22_class_head(T, gww):
     assert err < 5e-3
     sure = margin > 1e-2
     np.testing.assert_array_equal(logits.argmax(1)[sure], ref.argmax(1)[sure])
+
+
+def test_device_clustering_equals_the_reference_get_clusters_fixtures(T, gww, golden):
+    """``gww_cluster_triggers_f64`` (threshold + clustering where the scores were computed) against what the reference's
+    OWN ``get_clusters`` produced (``golden/inference_host.npz``, made by running the definitions of
+    ``MLGWSC-1/inference.py`` in the build container): the 40 s search fixture (392 windows, threshold 0.5 -> 211 triggers
+    -> 20 clusters) bit for bit, and the gap fixture (gaps drawn around 0.35 s, its float neighbours included, two keys)."""
+    from gw_whisper_amd import inference as inf, synth
+    g = golden("inference_host.npz")
+    strain = synth.strain_segments(2, seed=77, n_samples=2048 * 40)
+    sl = inf.DeviceSegmentSlicer(strain, start_time=np.float64(1000.25))
+    assert len(sl) == int(g["short_n_windows"]) == len(g["short_scores"])
+    t, v, tv = inf.cluster_triggers_device(sl.times(0, len(sl)), T.from_numpy(g["short_scores"]).cuda(), 0.5, 0.35)
+    np.testing.assert_array_equal(t, g["cl_short_times"])
+    np.testing.assert_array_equal(v, g["cl_short_vals"])
+    np.testing.assert_array_equal(tv, g["cl_short_tvars"])
+    # the gap fixture: every entry is a trigger (threshold below all values); keys are clustered separately and concatenated
+    t2, v2 = g["cl_in_times"], g["cl_in_vals"]
+    parts = [inf.cluster_triggers_device(T.from_numpy(t2[a:b]).cuda(), T.from_numpy(v2[a:b].astype(np.float32)).cuda(),
+                                         -1e30, 0.35) for a, b in ((0, 250), (250, 400))]
+    empty = inf.cluster_triggers_device(T.empty(0, dtype=T.float64).cuda(), T.empty(0).cuda(), -1e30, 0.35)
+    assert len(empty[0]) == 0
+    np.testing.assert_array_equal(np.concatenate([p[0] for p in parts]), g["cl_two_times"])
+    np.testing.assert_allclose(np.concatenate([p[1] for p in parts]), g["cl_two_vals"], rtol=1e-7)
+    # no trigger at all, one trigger, and a score array that is not a multiple of the wave
+    none = inf.cluster_triggers_device(sl.times(0, 100), T.zeros(100).cuda(), 0.5, 0.35)
+    assert len(none[0]) == 0
+    s1 = T.zeros(131).cuda(); s1[130] = 0.9
+    one = inf.cluster_triggers_device(sl.times(0, 131), s1, 0.5, 0.35)
+    assert len(one[0]) == 1 and one[0][0] == sl.times_host(0, 131)[130] and abs(one[1][0] - 0.9) < 1e-7
+    # through evaluate_slices: the third return value equals the host clustering of the returned triggers
+    from tests.helpers import search_toy_network
+    trig, vals, cl = inf.evaluate_slices(sl, search_toy_network().cuda(), trigger_threshold=0.5, cluster_threshold=0.35)
+    th, vh, _ = inf.get_clusters({"seg": trig}, 0.35)
+    np.testing.assert_array_equal(cl[0], th)
+    np.testing.assert_array_equal(cl[1], vh)
