@@ -19,6 +19,9 @@ namespace gww {
 
 namespace {
 constexpr int DH = 64, TB = 128, KB = 64;
+#ifndef GWW_ATTBWD_DQ_WAVES
+#define GWW_ATTBWD_DQ_WAVES 2   // workgroups per CU of k_attn_bwd_dq (3: 168 registers, 12 bytes of scratch; 48 KB of LDS each)
+#endif
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr int TILE_BYTES = KB * DH * 2;   // 8 KB
 
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void k_attn_rowdot(const unsigned short* __res
 }
 
 // ------------------------------------------------------------------------------------ dQ
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const unsigned short* __restrict__ qkv,
+__global__ __launch_bounds__(256, GWW_ATTBWD_DQ_WAVES) void k_attn_bwd_dq(const unsigned short* __restrict__ qkv,
                                                         const unsigned short* __restrict__ dctx,
                                                         const float* __restrict__ lse,
                                                         const float* __restrict__ Dv,
