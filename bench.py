@@ -407,6 +407,18 @@ def main():
                                          "pooled_ms_per_batch": ms_bp, "workload": "BASELINE configs[3] encoder (22-class head is torch.nn)"}
         del enc_b
         torch.cuda.empty_cache()
+        ds_, Ls_, Hs_, fs_ = synth.ENCODER_SIZES["small"]
+        enc_s = WhisperEncoder.from_numpy_state_dict(synth.named_encoder_state_dict("small", seed=0),
+                                                     WhisperConfig.named("small"), precision="bf16").to(dev)
+        with torch.no_grad():
+            ms_s = time_kernel(lambda: enc_s.forward_raw(mel[:64], want_hidden=True, want_last=True), iters=3, warm=1)
+        tf_s = 64 * flops_per_segment(ds_, Ls_, Hs_, fs_)["total"] / (ms_s * 1e-3) / 1e12
+        extra["whisper_small_forward"] = {"batch": 64, "ms_per_batch": ms_s, "segments_per_s_per_gpu": 64 / ms_s * 1e3,
+                                          "achieved_tflops_per_gpu": tf_s, "frac_of_bf16_mfma_peak": tf_s / MFMA_BF16_PEAK_TFLOPS,
+                                          "workload": "BASELINE configs[2] / [4] encoder (generic per-op path: LayerNorm kernel + "
+                                                      "k_gemm_bf16_v3 + attention)"}
+        del enc_s
+        torch.cuda.empty_cache()
         # the parity gate itself: GWW_PREC_F32 (exact fp32 MFMA, 1/16 of the bf16 rate) -- the mode whose logits match
         # the reference to 1e-7; the bf16 headline path is held to 1e-3 on logits / exact labels
         enc_f = WhisperEncoder.from_numpy_state_dict(synth.named_encoder_state_dict("tiny", seed=0),
