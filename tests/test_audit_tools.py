@@ -70,3 +70,22 @@ def test_asm_load_audit_flags_a_touch_before_the_covering_wait(tmp_path):
     assert rc == 1 and "HAZARD" in out
     rc, out = _run("audit_asm_loads.py", ld + "\ts_waitcnt vmcnt(0)\n\tv_mov_b32_e32 v20, v10\n", tmp_path)
     assert rc == 0 and "1 asm loads, 0 hazards" in out
+
+
+def test_spill_audit_flags_a_scratch_access_inside_a_loop_and_a_count_over_its_ceiling(tmp_path):
+    meta = ("amdhsa.kernels:\n  - .name:           _Z6kernelv\n    .private_segment_fixed_size: 8\n    .vgpr_count:     512\n"
+            "    .vgpr_spill_count: 2\n")
+    loop = ".LBB0_1:                                ; =>This Inner Loop Header: Depth=1\n\tscratch_load_dword v1, off, off offset:4\n\ts_cbranch_scc1 .LBB0_1\n"
+    flat = "\tscratch_store_dword off, v1, off offset:4\n.LBB0_2:\n\tscratch_load_dword v1, off, off offset:4\n"
+    def run(body, *ceil):
+        f = tmp_path / "k.s"
+        f.write_text(HEAD + body + TAIL + meta)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_spills.py"), str(f), "kernel", *ceil],
+                           capture_output=True, text=True)
+        return r.returncode, r.stdout
+    rc, out = run(flat, "kernel=2")
+    assert rc == 0 and "2 spilled VGPRs (ceiling 2), 0 scratch accesses inside loops" in out
+    rc, out = run(flat)                       # default ceiling 0
+    assert rc == 1 and "FAIL" in out
+    rc, out = run(flat + loop, "kernel=2")    # within the ceiling, but inside a loop
+    assert rc == 1 and "1 scratch accesses inside loops" in out
