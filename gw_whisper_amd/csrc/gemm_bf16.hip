@@ -370,19 +370,36 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v3(const unsigned short* _
 #pragma unroll
       for (int j = 0; j < 4; ++j) issue_piece(p, j);
   const int frow = lane & 15, fk = lane >> 4;
-  int stores_age = 0;   // > 0: an epilogue's stores may still sit in the queue behind the tile being waited for
-  for (int it = 0; it < total; ++it) {
-    // tile it was requested three tiles ago; younger: the pieces of tiles it + 1, it + 2 and the stores of an epilogue
-    // in one of the last two tiles
-    if (GWW_G3_ABL & 2) {
-    } else if (it + 2 < total) {
-      if (stores_age > 0 && !(GWW_G3_ABL & 1)) wait_vmcnt<2 * GLDS3 + STORES3>();
-      else wait_vmcnt<2 * GLDS3>();
-    } else {
-      wait_vmcnt<0>();
+  // ---- the two waves of a SIMD alternate: waves 4 .. 7 (group 1; wave w + 4 shares wave w's SIMD) run ONE PHASE behind
+  // waves 0 .. 3 (one extra barrier at the start, one for group 0 at the end), and a k-tile is two phases -- LOAD (the
+  // tile's 12 fragment reads, the four LDS-DMA pieces of tile it + 3, nothing for the matrix pipe) and MFMA (32 MFMAs,
+  // registers only).  Between two barriers one wave of every SIMD computes while its partner loads; in the first form of
+  // this kernel both did the same thing at the same time and every component was paid in full (profiles/r03_gemm_ablation.md).
+  //   * a tile's pieces are waited for by their issuers before the barrier that opens its FIRST reader's (group 0's) LOAD
+  //     phase: group 0 waits at the end of MFMA(it - 1), group 1 at the end of LOAD(it - 1);
+  //   * fragment reads are drained (lgkmcnt(0)) before the phase ends: the partner group's next LOAD phase requests tile
+  //     it + 3 into the stage tile it - 1 was read from.
+  const bool g1 = __builtin_amdgcn_readfirstlane(wave) >= 4;
+  int stores_age = 0;   // > 0: an epilogue's stores still sit in the queue in front of pieces this wave may wait for
+  auto wait_next = [&](int it) {   // this wave's pieces of tile it + 1; younger: tiles it + 2, it + 3 (+ an epilogue's stores)
+    if (GWW_G3_ABL & 2) return;
+    if (it + 1 < total) {
+      if (it + 3 < total) {
+        if (stores_age > 0 && !(GWW_G3_ABL & 1)) wait_vmcnt<2 * GLDS3 + STORES3>();
+        else wait_vmcnt<2 * GLDS3>();
+      } else {
+        wait_vmcnt<0>();
+      }
     }
     if (stores_age > 0) --stores_age;
-    __builtin_amdgcn_s_barrier();
+  };
+  if (!(GWW_G3_ABL & 2)) {
+    if (total > 2) wait_vmcnt<2 * GLDS3>();
+    else wait_vmcnt<0>();
+  }
+  if (g1) __builtin_amdgcn_s_barrier();
+  for (int it = 0; it < total; ++it) {
+    __builtin_amdgcn_s_barrier();                       // ---- LOAD(it)
     const unsigned char* As = lds + (it & (NST3 - 1)) * STAGE3_BYTES;
     const unsigned char* Ws = As + A3_BYTES;
     bf16x8 af[8], wf[4];
@@ -392,14 +409,20 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v3(const unsigned short* _
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       af[i] = *reinterpret_cast<const bf16x8*>(As + ((GWW_G3_ABL & 4) ? 0 : swz3(wm * 128 + i * 16 + frow, fk)));
-    const bool more = it + NST3 - 1 < total;
+    if (it + NST3 - 1 < total)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (more && (i & 1) == 0) issue_piece(it + NST3 - 1, i >> 1);   // one DMA piece per eight MFMAs
+      for (int j = 0; j < 4; ++j) issue_piece(it + NST3 - 1, j);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (g1) wait_next(it);
+    __builtin_amdgcn_s_barrier();                       // ---- MFMA(it)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-    }
+    __builtin_amdgcn_s_setprio(0);
     if ((it + 1) % nk == 0) {
       const int nn = nt0 + it / nk;
       // the bias of this lane's four column groups: asm reads -- hipcc cannot tell these LDS reads from the LDS-DMA
@@ -449,9 +472,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v3(const unsigned short* _
           }
         }
       }
-      stores_age = 3;   // the stores sit behind the pieces of tile it + 3: tiles it + 1 .. it + 3 may overtake them
+      // the stores sit behind the pieces of tile it + 3: group 0 still has the waits of tiles it + 1 .. it + 3 ahead that may
+      // leave them in flight, group 1 (whose wait for tile it + 1 is already behind it) two
+      stores_age = g1 ? 2 : 3;
     }
+    if (!g1) wait_next(it);
   }
+  if (!g1) __builtin_amdgcn_s_barrier();
 }
 
 static int pick_n_split(long panels, int tiles_n) {

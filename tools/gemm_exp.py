@@ -31,11 +31,17 @@ print(" | ".join(res))
 ''' % ROOT
 for m in sys.argv[1:] or ["ABL=0"]:
     tag = m.replace("=", "").replace(",", "_")
-    defs = [f"-DGWW_G3_{kv}" for kv in m.split(",")]
+    src = os.path.join(csrc, "gemm_bf16.hip")
+    defs = []
+    for kv in m.split(","):
+        if kv.startswith("SRC="):   # another form of the source file (kept next to the tool's outputs), same headers
+            src = os.path.join(ROOT, kv[4:])
+        else:
+            defs.append(f"-DGWW_G3_{kv}")
+    tag = tag.replace("/", "_").replace(".", "_")
     o = os.path.join(out, f"gemm_bf16_{tag}.o")
     so = os.path.join(out, f"libgww_{tag}.so")
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast", *defs, "-c",
-                    os.path.join(csrc, "gemm_bf16.hip"), "-o", o], check=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast", *defs, "-I", csrc, "-c", src, "-o", o], check=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + [o], check=True)
     r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, GWW_LIB=so), capture_output=True, text=True)
     print(f"{m}: {r.stdout.strip()} {r.stderr.strip()[-400:] if r.returncode else ''}", flush=True)
