@@ -319,7 +319,9 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* Aany, 
             v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3);
           }
           if constexpr (EPI == EPI_DGELU) {   // gelu'(z) = Phi(z) + z phi(z)  (train_ops.hip::k_gelu_bf16<true>)
-            auto dg = [](float z) { return 0.5f * (1.0f + erff(z * 0.70710678f)) + z * 0.3989422804f * __expf(-0.5f * z * z); };
+            // dgelu_fast (common.h): 16 VALU operations where ocml erff + expf took about sixty -- this epilogue's VALU work
+            // was five times the n-tile's MFMA time
+            auto dg = [](float z) { return dgelu_fast(z); };
             v0 = dg(v0); v1 = dg(v1); v2 = dg(v2); v3 = dg(v3);
           }
           u32x2 o = {pack2bf(v0, v1), pack2bf(v2, v3)};

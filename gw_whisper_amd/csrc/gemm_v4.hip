@@ -38,6 +38,9 @@
 
 namespace gww {
 
+#ifndef GWW_G4_DEEP
+#define GWW_G4_DEEP 0   // measured: no gain (the ring wait is not what bounds the loop), off
+#endif
 #ifndef GWW_G4_ORDER
 #define GWW_G4_ORDER 1
 #endif
@@ -172,6 +175,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
   // PRE (bf16 outputs): A0 of the NEXT k-tile is read in phase 3 of this one (fragment reads per phase 8 / 4 / 8 / 4 instead
   // of 12 / 4 / 8 / 0); the fp32-residual form has no 16 registers left for the second A0 set
   constexpr bool PRE = BF16OUT;
+  // DEEP (with PRE): every half-tile is requested as early as its LDS slot allows -- two phases behind the slot's last read:
+  // phase 0: W1(t+1), 1: A0(t+2), 2: W0(t+2), 3: A1(t+2) -- SIX phases (1.5 k-tiles) ahead of the first read, five half-tiles
+  // in flight behind every wait (vmcnt(10)); the A panel comes from HBM, and the ring wait was where its latency showed
+  constexpr bool DEEP = PRE && GWW_G4_DEEP;
+  constexpr int RING = DEEP ? 10 : 8;   // LDS-DMA operations a wait leaves in flight: five resp. four half-tiles
   bf16x8 af0[PRE ? 2 : 1][2][2], af1[2][2], wf[4][2];
 
   // ---- epilogue of one quadrant, in the LOAD section of the phase behind its last MFMAs (the partner wave of the SIMD is
@@ -280,8 +288,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
     const long w0 = (long)nt0 * 256 * K;
     stage(ic<0>{}, ic<0>{}, 0); stage(ic<0>{}, ic<2>{}, w0); stage(ic<0>{}, ic<1>{}, 0); stage(ic<0>{}, ic<3>{}, w0);
     stage(ic<1>{}, ic<0>{}, 64); stage(ic<1>{}, ic<2>{}, w0 + 64);
+    if constexpr (DEEP) stage(ic<1>{}, ic<1>{}, 64);
   }
-  if (!(GWW_G4_ABL & 2)) vm_wait<8>();   // (retires the residual preloads in front of the pieces, too)
+  if (!(GWW_G4_ABL & 2)) vm_wait<RING>();   // A0, W0 of k-tile 0 (and the residual preloads in front of the pieces)
   else vm_wait<0>();
   __builtin_amdgcn_s_barrier();
   // A0 of k-tile 0 for the leading phase (in the loop it is read one phase early, in phase 3 of the k-tile before)
@@ -293,29 +302,32 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
   }
   if (g1) __builtin_amdgcn_s_barrier();
 
-  int kt = 0, nn = nt0;   // k-tile t is k-tile kt of n-tile nn
+  // ---- stream cursors (scalar, advanced inside the last MFMA section of a k-tile, where the wave's issue slots are idle):
+  // k-tile t is k-tile kt of n-tile nn; (ao1, wo1) / (ao2, wo2) = element offsets of k-tiles t + 1 / t + 2 in A resp. W,
+  // CLAMPED to the last k-tile of the work item -- past the end the ring keeps requesting that tile into slots nobody reads
+  // again, so every wait of the loop sees the same queue (no tail cases; one vmcnt(0) before the kernel ends)
+  int kt = 0, nn = nt0;
+  const unsigned w_tile = 256u * (unsigned)K;
+  unsigned ao1 = 64, wo1 = (unsigned)nt0 * w_tile + 64;   // nk >= 2
+  int k2 = 2, n2 = nt0;
+  if (k2 == nk) { k2 = 0; ++n2; }
+  if (total <= 2) { k2 = 1; n2 = nt0; }
+  unsigned ao2 = (unsigned)k2 << 6, wo2 = (unsigned)n2 * w_tile + ao2;
   G4S_DECL
 
-  // one wait of the ring: the four youngest half-tiles (+ EXTRA stores of epilogue quadrants, when `epi`) stay in flight
-  auto ring_wait = [&](bool stream_on, bool epi, auto extra_c) {
+  // one wait of the ring: the youngest RING LDS-DMA operations (+ EXTRA stores of epilogue quadrants, when `epi`) stay in flight
+  auto ring_wait = [&](int epi, auto extra_c) {
     constexpr int EXTRA = decltype(extra_c)::value;
     if (GWW_G4_ABL & 2) return;
-    if (!stream_on) vm_wait<0>();
-    else if (epi && !(GWW_G4_ABL & 1)) vm_wait<(8 + EXTRA > 63 ? 63 : 8 + EXTRA)>();
-    else vm_wait<8>();
+    if (EXTRA > 0 && epi && !(GWW_G4_ABL & 1)) vm_wait<(RING + EXTRA > 63 ? 63 : RING + EXTRA)>();
+    else vm_wait<RING>();
   };
 
   auto ktile = [&](int t, auto buf_c) {
     constexpr int B = decltype(buf_c)::value;
-    int k1 = kt + 1, n1 = nn;
-    if (k1 == nk) { k1 = 0; ++n1; }
-    int k2 = k1 + 1, n2 = n1;
-    if (k2 == nk) { k2 = 0; ++n2; }
-    const bool has1 = t + 1 < total, has2 = t + 2 < total;
-    const long ao1 = (long)k1 << 6, wo1 = (long)n1 * 256 * K + ao1;
-    const long ao2 = (long)k2 << 6, wo2 = (long)n2 * 256 * K + ao2;
-    const bool last = (B == 1) && kt == nk - 1;        // this k-tile completes n-tile nn (nk is even: only in buffer 1)
-    const bool first = (B == 0) && kt == 0 && t > 0;   // the k-tile before completed n-tile nn - 1
+    const int last = (B == 1) && kt == nk - 1;        // this k-tile completes n-tile nn (nk is even: only in buffer 1)
+    const int first = (B == 0) && kt == 0 && t > 0;   // the k-tile before completed n-tile nn - 1
+    const int second = (B == 1) && kt == 1 && t > 1;  // ... the k-tile before that one did
 
     auto mid = [&](auto p_c) {   // between the two sections of a phase
       __builtin_amdgcn_s_barrier();
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
       G4S(decltype(p_c)::value, 0)
       __builtin_amdgcn_s_setprio(1);
     };
-    auto mfma16 = [&](auto ah_c, auto wh_c) {
+    auto mfma16 = [&](auto ah_c, auto wh_c, auto&& tail) {
       constexpr int AH = decltype(ah_c)::value, WH = decltype(wh_c)::value;
       constexpr int PH = AH == 0 ? (WH == 0 ? 0 : 3) : (WH == 0 ? 1 : 2);
 #pragma unroll
@@ -335,14 +347,16 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
           for (int j = 0; j < 4; ++j)
             acc[AH][WH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], AH ? af1[i][ks] : af0[PRE ? B : 0][i][ks],
                                                                         acc[AH][WH][i][j], 0, 0, 0);
+      tail();
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       G4S(PH, 1)
       __builtin_amdgcn_s_barrier();
       G4S(PH, 2)
     };
+    auto none = []() {};
 
-    // ---- phase 0: quadrant (A0, W0).  W0 fragments (A0's were read in the phase before); requests A1(t+1); retires A1(t)
+    // ---- phase 0: quadrant (A0, W0).  W0 fragments (PRE: A0's were read in the phase before)
     if constexpr (B == 0) { if (first) epi_quadrant(ic<0>{}, ic<1>{}, nn - 1); }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -354,62 +368,98 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
 #pragma unroll
         for (int i = 0; i < 2; ++i) af0[0][i][ks] = *reinterpret_cast<const bf16x8*>(a_rd[B][ks] + i * 2048);
     }
-    if (has1) stage(ic<1 - B>{}, ic<1>{}, ao1);
-    __builtin_amdgcn_sched_barrier(0);
-    ring_wait(has1, first, ic<4 * SQ>{});
+    if constexpr (DEEP) {   // requests W1(t+1); retires A1(t)
+      stage(ic<1 - B>{}, ic<3>{}, wo1);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (B == 0) ring_wait(first, ic<4 * SQ>{});
+      else ring_wait(second, ic<SQ>{});
+    } else {                // requests A1(t+1); retires A1(t)
+      stage(ic<1 - B>{}, ic<1>{}, ao1);
+      __builtin_amdgcn_sched_barrier(0);
+      ring_wait(first, ic<(B == 0 ? 4 * SQ : 0)>{});
+    }
     mid(ic<0>{});
-    mfma16(ic<0>{}, ic<0>{});
+    mfma16(ic<0>{}, ic<0>{}, none);
 
-    // ---- phase 1: quadrant (A1, W0).  A1 fragments; requests W1(t+1); retires W1(t)
+    // ---- phase 1: quadrant (A1, W0).  A1 fragments
     if constexpr (B == 1) { if (last) epi_quadrant(ic<0>{}, ic<0>{}, nn); }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i) af1[i][ks] = *reinterpret_cast<const bf16x8*>(a_rd[B][ks] + HT4 + i * 2048);
-    if (has1) stage(ic<1 - B>{}, ic<3>{}, wo1);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (B == 1) ring_wait(has1, last, ic<SQ>{});
-    else ring_wait(has1, first, ic<3 * SQ>{});
+    if constexpr (DEEP) {   // requests A0(t+2); retires W1(t)
+      stage(ic<B>{}, ic<0>{}, ao2);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (B == 1) ring_wait(last, ic<SQ>{});
+      else ring_wait(first, ic<4 * SQ>{});
+    } else {                // requests W1(t+1); retires W1(t)
+      stage(ic<1 - B>{}, ic<3>{}, wo1);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (B == 1) ring_wait(last, ic<SQ>{});
+      else ring_wait(first, ic<3 * SQ>{});
+    }
     mid(ic<1>{});
-    mfma16(ic<1>{}, ic<0>{});
+    mfma16(ic<1>{}, ic<0>{}, none);
 
-    // ---- phase 2: quadrant (A1, W1).  W1 fragments; requests A0(t+2); retires A0(t+1) (read in phase 3)
+    // ---- phase 2: quadrant (A1, W1).  W1 fragments
     if constexpr (B == 1) { if (last) epi_quadrant(ic<1>{}, ic<0>{}, nn); }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int j = 0; j < 4; ++j) wf[j][ks] = *reinterpret_cast<const bf16x8*>(w_rd[B][ks] + HT4 + j * 2048);
-    if (has2) stage(ic<B>{}, ic<0>{}, ao2);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (B == 1) ring_wait(has2, last, ic<2 * SQ>{});
-    else ring_wait(has2, first, ic<2 * SQ>{});
+    if constexpr (DEEP) {   // requests W0(t+2); retires A0(t+1) (read in phase 3)
+      stage(ic<B>{}, ic<2>{}, wo2);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (B == 1) ring_wait(last, ic<2 * SQ>{});
+      else ring_wait(first, ic<3 * SQ>{});
+    } else {                // requests A0(t+2); retires A0(t+1) (PRE: read in phase 3; fp32 residual: the preloads of quadrant 2)
+      stage(ic<B>{}, ic<0>{}, ao2);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (B == 1) ring_wait(last, ic<2 * SQ>{});
+      else ring_wait(first, ic<2 * SQ>{});
+    }
     mid(ic<2>{});
-    mfma16(ic<1>{}, ic<1>{});
+    mfma16(ic<1>{}, ic<1>{}, none);
 
-    // ---- phase 3: quadrant (A0, W1).  A0 fragments of k-tile t + 1; requests W0(t+2); retires W0(t+1)
+    // ---- phase 3: quadrant (A0, W1).  PRE: A0 fragments of k-tile t + 1
     if constexpr (B == 1) { if (last) epi_quadrant(ic<1>{}, ic<1>{}, nn); }
     if constexpr (PRE) {
-      if (has1) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) af0[1 - B][i][ks] = *reinterpret_cast<const bf16x8*>(a_rd[1 - B][ks] + i * 2048);
-      }
+        for (int i = 0; i < 2; ++i) af0[1 - B][i][ks] = *reinterpret_cast<const bf16x8*>(a_rd[1 - B][ks] + i * 2048);
     }
-    if (has2) stage(ic<B>{}, ic<2>{}, wo2);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (B == 1) ring_wait(has2, last, ic<3 * SQ>{});
-    else ring_wait(has2, first, ic<(BF16OUT ? SQ : 0)>{});
+    if constexpr (DEEP) {   // requests A1(t+2); retires W0(t+1)
+      stage(ic<B>{}, ic<1>{}, ao2);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (B == 1) ring_wait(last, ic<3 * SQ>{});
+      else ring_wait(first, ic<2 * SQ>{});
+    } else {                // requests W0(t+2); retires W0(t+1) (and, fp32 residual, the preloads of quadrant 3: no allowance)
+      stage(ic<B>{}, ic<2>{}, wo2);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (B == 1) ring_wait(last, ic<3 * SQ>{});
+      else ring_wait(first, ic<(BF16OUT ? SQ : 0)>{});
+    }
     mid(ic<3>{});
-    mfma16(ic<0>{}, ic<1>{});
-
-    kt = k1; nn = n1;
+    mfma16(ic<0>{}, ic<1>{}, [&]() {
+      // cursors of the next k-tile (scalar work under the MFMAs)
+      ++kt;
+      if (kt == nk) { kt = 0; ++nn; }
+      ao1 = ao2; wo1 = wo2;
+      if (t + 3 < total) {
+        ++k2;
+        if (k2 == nk) { k2 = 0; ++n2; }
+        ao2 = (unsigned)k2 << 6;
+        wo2 = (unsigned)n2 * w_tile + ao2;
+      }
+    });
   };
 
   for (int t = 0; t < total; t += 2) {
     ktile(t, ic<0>{});
     ktile(t + 1, ic<1>{});
   }
+  vm_wait<0>();   // the clamped requests behind the last k-tile: no LDS-DMA may be in flight when the workgroup ends
   G4S_FLUSH
   epi_quadrant(ic<0>{}, ic<1>{}, nt1 - 1);
   if (!g1) __builtin_amdgcn_s_barrier();

@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void k_gelu_bf16(const unsigned short* __restr
       float r0, r1;
       if constexpr (BWD) {
         // gelu'(z) = Phi(z) + z phi(z)
-        const float p0 = 0.5f * (1.0f + erff(z0 * 0.70710678f)) + z0 * 0.3989422804f * __expf(-0.5f * z0 * z0);
-        const float p1 = 0.5f * (1.0f + erff(z1 * 0.70710678f)) + z1 * 0.3989422804f * __expf(-0.5f * z1 * z1);
+        const float p0 = dgelu_fast(z0);
+        const float p1 = dgelu_fast(z1);
         r0 = bf2f((unsigned short)(dv[j] & 0xffff)) * p0;
         r1 = bf2f((unsigned short)(dv[j] >> 16)) * p1;
       } else {
@@ -168,7 +168,7 @@ int launch_transpose_bf16(const void* in, void* out, int R, int Cn, hipStream_t 
 // overlapping rows of token-major padded buffers (encoder.hip), so their input gradients are a GEMM against
 // the transposed panel ("col" rows = taps side by side) followed by a gather over the taps -- no atomics.
 __device__ __forceinline__ float gelu_grad(float z) {   // Phi(z) + z phi(z)
-  return 0.5f * (1.0f + erff(z * 0.70710678f)) + z * 0.3989422804f * __expf(-0.5f * z * z);
+  return dgelu_fast(z);
 }
 
 // dz2[b (T+1) + t] = t < T ? bf16(dx0[b T + t]) * gelu'(z2[b (T+1) + t]) : 0        (8 columns per thread)
