@@ -27,9 +27,9 @@
 //   * D = W-fragment x A-fragment: a lane holds four consecutive output columns of one row; v_permlane16_swap pairs
 //     two 16-column tiles so that every lane stores 16 bytes (64 contiguous bytes per row and instruction).
 //
-// Work item = (column split, row panel) in the split-major, XCD-contiguous order of v3; a block walks the n-tiles of
-// its split with the k-tile stream running through the epilogues.  Requires N % 256 == 0, K % 128 == 0, the row count
-// padded to 256 by the caller (rows_padded_256).
+// Work item = (row panel, column split), panel-major and XCD-contiguous; at most one block per CU, whose k-tile stream
+// runs through the epilogues of its tiles AND through its items.  Requires N % 256 == 0, N <= 3072 (the bias vector lives
+// in LDS), K % 128 == 0, the row count padded to 256 by the caller (rows_padded_256).
 
 #include "common.h"
 #include "epilogue.h"
@@ -40,12 +40,6 @@ namespace gww {
 
 #ifndef GWW_G4_DEEP
 #define GWW_G4_DEEP 0   // measured: no gain (the ring wait is not what bounds the loop), off
-#endif
-#ifndef GWW_G4_ORDER
-#define GWW_G4_ORDER 1
-#endif
-#ifndef GWW_G4_STAG
-#define GWW_G4_STAG 0
 #endif
 #ifndef GWW_G4_ABL
 #define GWW_G4_ABL 0   // diagnostic builds only (wrong results): 1 = no epilogue stores, 2 = no LDS-DMA / ring waits, 4 = no fragment reads
@@ -69,6 +63,7 @@ namespace {
 constexpr int HT4 = 128 * 64 * 2;   // half-tile: 128 rows x 64 k, bf16
 constexpr int BUF4 = 4 * HT4;       // A0 A1 W0 W1
 constexpr int OFF_A4 = 0, OFF_W4 = 2 * HT4;
+constexpr int BIAS4 = 3072;         // the whole bias vector lives in LDS: N <= 3072 (whisper-small's fc1)
 
 template <int N>
 __device__ __forceinline__ void vm_wait() {
@@ -94,9 +89,9 @@ template <int EPI>
 __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* __restrict__ A, long lda,
                                                          const unsigned short* __restrict__ W,
                                                          const float* __restrict__ bias, const float* resid,
-                                                         void* C, long M, int N, int K, int tiles_n, int n_split) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF4 + 1536 * 4];
-  float* lds_bias = reinterpret_cast<float*>(lds + 2 * BUF4);
+                                                         void* C, long M, int N, int K, int n_split, int tpi, int n_items) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF4 + BIAS4 * 4];
+  float* lds_bias = reinterpret_cast<float*>(lds + 2 * BUF4);   // the whole bias vector (N <= BIAS4)
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* g_ptr;
   constexpr bool BF16OUT = EPI != EPI_RESID;
@@ -104,30 +99,38 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
   float* const Cf = reinterpret_cast<float*>(C);   // (EPI_RESID: may alias resid)
   constexpr int SQ = BF16OUT ? 4 : 8;              // stores per thread and output QUADRANT
 
-  const int panels = (int)(gridDim.x / n_split);
-  int item;
-  {
-    const int nb = (int)gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    item = xcd * per + (xcd < rem ? xcd : rem) + idx;
-  }
-  int split = item / panels, panel = item - split * panels;
-  if (GWW_G4_ORDER) { panel = item / n_split; split = item - panel * n_split; }   // panel-major: the splits of a panel run side by side on one XCD
-  const int nt0 = (int)((long)split * tiles_n / n_split), nt1 = (int)((long)(split + 1) * tiles_n / n_split);
-  const long m0 = (long)panel * 256;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const bool g1 = wave >= 4;
   const int nk = K >> 6;
-  const int total = (nt1 - nt0) * nk;
 
-  for (int i = tid; i < (nt1 - nt0) * 256; i += 512) lds_bias[i] = bias ? bias[nt0 * 256 + i] : 0.f;
-#if GWW_G4_STAG
-  if (blockIdx.x < 256) {   // diagnostic: the first round of workgroups starts spread over one output tile's period
-    const int ph = (blockIdx.x >> 3) & 7;
-    for (int i = 0; i < ph * nk * GWW_G4_STAG / 12; ++i) __builtin_amdgcn_s_sleep(127);
+  // ---- the work items of this block.  Item = (row panel, column split), panel-major (the splits of a panel run side by
+  // side and share its A panel through the L2); the items are cut into eight contiguous chunks, one per XCD (blockIdx % 8),
+  // and the blocks of an XCD walk their chunk with the stride of their number: one launch of at most one block per CU, the
+  // k-tile stream of a block runs THROUGH its items (the ring requests the next item's first k-tiles under the last
+  // MFMAs of this one: no pipeline fill and drain per item -- whisper-base's items are one or two tiles of eight k-tiles)
+  int first_item, item_stride, n_my;
+  {
+    const int G = (int)gridDim.x, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int per = n_items >> 3, rem = n_items & 7;
+    const int c0 = xcd * per + (xcd < rem ? xcd : rem), clen = per + (xcd < rem ? 1 : 0);
+    item_stride = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
+    first_item = c0 + bi;
+    n_my = (clen - bi + item_stride - 1) / item_stride;
   }
-#endif
+  const int n_tiles = n_my * tpi;
+  const int total = n_tiles * nk;
+  // tile i of this block -> first row and column tile
+  auto desc = [&](int i, long& m0, int& ncol) {
+    const int j = i / tpi, nn_i = i - j * tpi;
+    const int item = first_item + j * item_stride;
+    const int panel = item / n_split, split = item - panel * n_split;
+    m0 = (long)panel * 256;
+    ncol = split * tpi + nn_i;
+  };
+
+  for (int i = tid; i < N; i += 512) lds_bias[i] = bias ? bias[i] : 0.f;
 
   // ---- LDS-DMA: half-tile h of an operand = 16 pieces of 8 rows; wave w requests pieces 2 w, 2 w + 1 (rows 16 w ..).
   // Lane l lands at row l >> 3, position l & 7 of its piece, which holds chunk (l & 7) ^ ((row >> 1) & 7) of that row.
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
   for (int j = 0; j < 2; ++j) {
     const int row = 16 * wave + 8 * j + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    a_src[j] = A + (((GWW_G4_ABL & 16) ? 0 : m0) + row) * lda + chunk * 8;   // 16: every block reads panel 0 (L2-resident A)
+    a_src[j] = A + (long)row * lda + chunk * 8;
     w_src[j] = W + (long)row * K + chunk * 8;
   }
   const long a_half = 128 * lda, w_half = 128L * K;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
   // in its MFMA section): bias (+ GELU), pack, store; EPI_RESID: the fp32 residual tile was loaded INTO the accumulators
   // before the n-tile's first MFMA, so this is add-bias + store, and the next n-tile's residual is requested into the
   // registers just freed (asm loads: counted by hand with the ring, retired by the waits in front of their first MFMA)
-  auto preload_resid = [&](auto ah_c, auto wh_c, int nn) {
+  auto preload_resid = [&](auto ah_c, auto wh_c, long m0, int nn) {
     constexpr int ah = decltype(ah_c)::value, wh = decltype(wh_c)::value;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -200,11 +203,12 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
       }
     }
   };
-  auto epi_quadrant = [&](auto ah_c, auto wh_c, int nn) {
+  // (m0, nn): the finished tile; (pre, m0n, nnn): fp32 residual -- the tile whose residual goes into the freed registers
+  auto epi_quadrant = [&](auto ah_c, auto wh_c, long m0, int nn, int pre, long m0n, int nnn) {
     constexpr int ah = decltype(ah_c)::value, wh = decltype(wh_c)::value;
     f32x4 bvj[4];
     {
-      const unsigned ba = (unsigned)(unsigned long long)(lds_ptr)(lds_bias + (nn - nt0) * 256 + wh * 128 + wc * 64 + (lane >> 4) * 4);
+      const unsigned ba = (unsigned)(unsigned long long)(lds_ptr)(lds_bias + nn * 256 + wh * 128 + wc * 64 + (lane >> 4) * 4);
       asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
                    "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(bvj[0]), "=&v"(bvj[1]), "=&v"(bvj[2]), "=&v"(bvj[3]) : "v"(ba));
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
     const int cbase = nn * 256 + wh * 128 + wc * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const long m = ((GWW_G4_ABL & 8) ? 0 : m0) + ah * 128 + wr * 32 + i * 16 + (lane & 15);   // 8: every block stores into panel 0
+      const long m = m0 + ah * 128 + wr * 32 + i * 16 + (lane & 15);
       if constexpr (BF16OUT) {
 #pragma unroll
         for (int jp = 0; jp < 4; jp += 2) {
@@ -249,8 +253,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
       }
     }
     if constexpr (!BF16OUT) {
-      if (nn + 1 < nt1 && !(GWW_G4_ABL & 1)) {
-        preload_resid(ah_c, wh_c, nn + 1);
+      if (pre && !(GWW_G4_ABL & 1)) {
+        preload_resid(ah_c, wh_c, m0n, nnn);
       } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -259,6 +263,12 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
       }
     }
   };
+
+  // ---- the tiles around the stream position: cur = the tile of k-tile t, prev / next its neighbours in this block's order
+  long m0c, m0p = 0, m0n = 0;
+  int ncolc, ncolp = 0, ncoln = 0, tile_i = 0, has_next = n_tiles > 1;
+  desc(0, m0c, ncolc);
+  if (has_next) desc(1, m0n, ncoln);
 
   if constexpr (BF16OUT) {
 #pragma unroll
@@ -279,16 +289,16 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   } else {
-    preload_resid(ic<0>{}, ic<0>{}, nt0); preload_resid(ic<1>{}, ic<0>{}, nt0);
-    preload_resid(ic<1>{}, ic<1>{}, nt0); preload_resid(ic<0>{}, ic<1>{}, nt0);
+    preload_resid(ic<0>{}, ic<0>{}, m0c, ncolc); preload_resid(ic<1>{}, ic<0>{}, m0c, ncolc);
+    preload_resid(ic<1>{}, ic<1>{}, m0c, ncolc); preload_resid(ic<0>{}, ic<1>{}, m0c, ncolc);
   }
 
   // ---- prologue: what phases (-1, 2) .. would have requested: k-tile 0 whole, A0 and W0 of k-tile 1 (nk >= 2)
   {
-    const long w0 = (long)nt0 * 256 * K;
-    stage(ic<0>{}, ic<0>{}, 0); stage(ic<0>{}, ic<2>{}, w0); stage(ic<0>{}, ic<1>{}, 0); stage(ic<0>{}, ic<3>{}, w0);
-    stage(ic<1>{}, ic<0>{}, 64); stage(ic<1>{}, ic<2>{}, w0 + 64);
-    if constexpr (DEEP) stage(ic<1>{}, ic<1>{}, 64);
+    const long a0 = m0c * lda, w0 = (long)ncolc * 256 * K;
+    stage(ic<0>{}, ic<0>{}, a0); stage(ic<0>{}, ic<2>{}, w0); stage(ic<0>{}, ic<1>{}, a0); stage(ic<0>{}, ic<3>{}, w0);
+    stage(ic<1>{}, ic<0>{}, a0 + 64); stage(ic<1>{}, ic<2>{}, w0 + 64);
+    if constexpr (DEEP) stage(ic<1>{}, ic<1>{}, a0 + 64);
   }
   if (!(GWW_G4_ABL & 2)) vm_wait<RING>();   // A0, W0 of k-tile 0 (and the residual preloads in front of the pieces)
   else vm_wait<0>();
@@ -303,16 +313,18 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
   if (g1) __builtin_amdgcn_s_barrier();
 
   // ---- stream cursors (scalar, advanced inside the last MFMA section of a k-tile, where the wave's issue slots are idle):
-  // k-tile t is k-tile kt of n-tile nn; (ao1, wo1) / (ao2, wo2) = element offsets of k-tiles t + 1 / t + 2 in A resp. W,
-  // CLAMPED to the last k-tile of the work item -- past the end the ring keeps requesting that tile into slots nobody reads
+  // k-tile t is k-tile kt of tile `cur`; (ao1, wo1) / (ao2, wo2) = element offsets of k-tiles t + 1 / t + 2 in A resp. W,
+  // CLAMPED to the last k-tile of the block's stream -- past the end the ring keeps requesting that tile into slots nobody reads
   // again, so every wait of the loop sees the same queue (no tail cases; one vmcnt(0) before the kernel ends)
-  int kt = 0, nn = nt0;
-  const unsigned w_tile = 256u * (unsigned)K;
-  unsigned ao1 = 64, wo1 = (unsigned)nt0 * w_tile + 64;   // nk >= 2
-  int k2 = 2, n2 = nt0;
-  if (k2 == nk) { k2 = 0; ++n2; }
-  if (total <= 2) { k2 = 1; n2 = nt0; }
-  unsigned ao2 = (unsigned)k2 << 6, wo2 = (unsigned)n2 * w_tile + ao2;
+  int kt = 0;
+  const long w_tile = 256L * K;
+  long ao1 = m0c * lda + 64, wo1 = ncolc * w_tile + 64;   // nk >= 2
+  int k2 = 2, tile2 = 0;
+  long m02 = m0c;
+  int ncol2 = ncolc;
+  if (total <= 2) k2 = 1;
+  else if (k2 == nk) { k2 = 0; tile2 = 1; m02 = m0n; ncol2 = ncoln; }
+  long ao2 = m02 * lda + ((long)k2 << 6), wo2 = ncol2 * w_tile + ((long)k2 << 6);
   G4S_DECL
 
   // one wait of the ring: the youngest RING LDS-DMA operations (+ EXTRA stores of epilogue quadrants, when `epi`) stay in flight
@@ -325,8 +337,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
 
   auto ktile = [&](int t, auto buf_c) {
     constexpr int B = decltype(buf_c)::value;
-    const int last = (B == 1) && kt == nk - 1;        // this k-tile completes n-tile nn (nk is even: only in buffer 1)
-    const int first = (B == 0) && kt == 0 && t > 0;   // the k-tile before completed n-tile nn - 1
+    const int last = (B == 1) && kt == nk - 1;        // this k-tile completes tile cur (nk is even: only in buffer 1)
+    const int first = (B == 0) && kt == 0 && t > 0;   // the k-tile before completed tile prev
     const int second = (B == 1) && kt == 1 && t > 1;  // ... the k-tile before that one did
 
     auto mid = [&](auto p_c) {   // between the two sections of a phase
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
     auto none = []() {};
 
     // ---- phase 0: quadrant (A0, W0).  W0 fragments (PRE: A0's were read in the phase before)
-    if constexpr (B == 0) { if (first) epi_quadrant(ic<0>{}, ic<1>{}, nn - 1); }
+    if constexpr (B == 0) { if (first) epi_quadrant(ic<0>{}, ic<1>{}, m0p, ncolp, 1, m0c, ncolc); }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -382,7 +394,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
     mfma16(ic<0>{}, ic<0>{}, none);
 
     // ---- phase 1: quadrant (A1, W0).  A1 fragments
-    if constexpr (B == 1) { if (last) epi_quadrant(ic<0>{}, ic<0>{}, nn); }
+    if constexpr (B == 1) { if (last) epi_quadrant(ic<0>{}, ic<0>{}, m0c, ncolc, has_next, m0n, ncoln); }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
     mfma16(ic<1>{}, ic<0>{}, none);
 
     // ---- phase 2: quadrant (A1, W1).  W1 fragments
-    if constexpr (B == 1) { if (last) epi_quadrant(ic<1>{}, ic<0>{}, nn); }
+    if constexpr (B == 1) { if (last) epi_quadrant(ic<1>{}, ic<0>{}, m0c, ncolc, has_next, m0n, ncoln); }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -422,7 +434,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
     mfma16(ic<1>{}, ic<1>{}, none);
 
     // ---- phase 3: quadrant (A0, W1).  PRE: A0 fragments of k-tile t + 1
-    if constexpr (B == 1) { if (last) epi_quadrant(ic<1>{}, ic<1>{}, nn); }
+    if constexpr (B == 1) { if (last) epi_quadrant(ic<1>{}, ic<1>{}, m0c, ncolc, has_next, m0n, ncoln); }
     if constexpr (PRE) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -444,13 +456,19 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
     mfma16(ic<0>{}, ic<1>{}, [&]() {
       // cursors of the next k-tile (scalar work under the MFMAs)
       ++kt;
-      if (kt == nk) { kt = 0; ++nn; }
+      if (kt == nk) {   // the next k-tile opens the next tile
+        kt = 0;
+        m0p = m0c; ncolp = ncolc; m0c = m0n; ncolc = ncoln;
+        ++tile_i;
+        has_next = tile_i + 1 < n_tiles;
+        if (has_next) desc(tile_i + 1, m0n, ncoln);
+      }
       ao1 = ao2; wo1 = wo2;
       if (t + 3 < total) {
         ++k2;
-        if (k2 == nk) { k2 = 0; ++n2; }
-        ao2 = (unsigned)k2 << 6;
-        wo2 = (unsigned)n2 * w_tile + ao2;
+        if (k2 == nk) { k2 = 0; ++tile2; desc(tile2, m02, ncol2); }
+        ao2 = m02 * lda + ((long)k2 << 6);
+        wo2 = ncol2 * w_tile + ((long)k2 << 6);
       }
     });
   };
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
   }
   vm_wait<0>();   // the clamped requests behind the last k-tile: no LDS-DMA may be in flight when the workgroup ends
   G4S_FLUSH
-  epi_quadrant(ic<0>{}, ic<1>{}, nt1 - 1);
+  epi_quadrant(ic<0>{}, ic<1>{}, m0p, ncolp, 0, 0L, 0);   // (the last k-tile's cursor step made the last tile `prev`)
   if (!g1) __builtin_amdgcn_s_barrier();
 }
 
@@ -470,23 +488,35 @@ int launch_gemm_bf16_v4(const void* A, long lda, const void* W, const float* bia
                         int N, int K, int epi, hipStream_t s) {
   // (no lower bound on M: a segment's rows must not depend on how many segments share the launch -- the batch-independence
   // property the tests check bit for bit -- so the kernel choice may depend on N and K only)
-  if (N % 256 != 0 || K % 128 != 0 || N > 12288 || M < 1) return -1;
+  if (N % 256 != 0 || K % 128 != 0 || N > BIAS4 || M < 1) return -1;
   if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID)) return -1;
   const long panels = cdiv(M, 256);
   const int tn = N / 256;
-  // column splits: a split's W slice should sit in one XCD's 4-MB L2 beside the streaming A panels (<= 1.5 MB), and its
-  // bias slice in 1536 floats of LDS (<= 6 n-tiles)
+  // column splits: a split's W slice should sit in one XCD's 4-MB L2 beside the streaming A panels (<= 1.5 MB); enough
+  // items for an even load over the CUs
   long fit = (3L << 19) / (256L * K * 2);
   if (fit < 1) fit = 1;
   if (fit > 6) fit = 6;
   int n_split = tn;
   for (int s2 = 1; s2 <= tn; ++s2)
     if (tn % s2 == 0 && tn / s2 <= fit && (panels * s2 >= 768 || s2 == tn)) { n_split = s2; break; }
-  dim3 grid((unsigned)(panels * n_split)), block(512);
+  const long n_items = panels * n_split;
+  GWW_REQUIRE(n_items < 2147483647L, "gemm_bf16: grid too large");
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    GWW_HIP(hipGetDevice(&dev));
+    GWW_HIP(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  // one block per CU at most (140 KB of LDS each); a block's k-tile stream runs through its items
+  dim3 grid((unsigned)(n_items < n_cu ? n_items : n_cu)), block(512);
+  const int tpi = tn / n_split;
 #define GWW_GEMM4_CASE(E)                                                                             \
   case E:                                                                                             \
     hipLaunchKernelGGL((k_gemm_bf16_v4<E>), grid, block, 0, s, (const unsigned short*)A, lda,         \
-                       (const unsigned short*)W, bias, resid, C, M, N, K, tn, n_split);               \
+                       (const unsigned short*)W, bias, resid, C, M, N, K, n_split, tpi, (int)n_items); \
     break;
   switch (epi) {
     GWW_GEMM4_CASE(EPI_BIAS) GWW_GEMM4_CASE(EPI_GELU) GWW_GEMM4_CASE(EPI_RESID)
