@@ -112,7 +112,11 @@ def test_cast_bf16_round_to_nearest_even(T, gww):
                                    # M % 256 == 0 and >= 4096: the persistent row-panel kernel (v2)
                                    (4096, 384, 384), (5120, 1152, 384), (4352, 384, 1536), (4096, 1536, 384), (8192, 128, 128),
                                    # whisper-small widths: N > 1536 runs the same kernel with the columns split over blocks
-                                   (4096, 2304, 768), (4352, 3072, 768), (4096, 768, 3072), (4096, 5120, 128)])
+                                   (4096, 2304, 768), (4352, 3072, 768), (4096, 768, 3072), (4096, 5120, 128),
+                                   # k_gemm_bf16_v4 (N % 256 == 0, N <= 3072, K % 128 == 0, M % 256 == 0): the smallest stream (one
+                                   # tile of two k-tiles), one item per block, and MORE items than CUs -- a block's k-tile stream then
+                                   # runs through several (panel, split) items: 300 / 260 panels x 2 / 1 splits
+                                   (256, 256, 128), (512, 512, 256), (76800, 512, 256), (66560, 256, 384), (2560, 3072, 128)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_bf16(T, gww, M, N, K, epi):
     from gw_whisper_amd import ops
