@@ -811,6 +811,317 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Two-waves-per-SIMD "ping-pong" form (GWW_ATT_VAR = 8; correct -- every test_attention_log2q case runs it too -- but
+// MEASURED SLOWER than the three-waves-per-SIMD default: 1.10 - 1.21 ms against 0.98 - 1.03 per whisper-tiny layer at
+// B = 256, with any of the priority settings below; kept as the starting point of a hand-placed version): a workgroup = 8 waves = 256 query rows of one
+// (b, h); waves w and w + 4 share a SIMD and run ONE BARRIER apart.  A 64-key tile is two sections per wave:
+//   M section: S(j) = K(j) Q^T (9 - 10 MFMAs, the running reference enters as the first of them) and, software-pipelined,
+//              O += V(j-1)^T P(j-1)^T (8 MFMAs) -- fragment reads, MFMAs, the LDS-DMA request of tile j + 2, nothing else;
+//   V section: the softmax of tile j on the vector ALU -- 32 v_exp_f32, the row sum, 16 v_cvt_pk -- and nothing else.
+// Between two barriers one wave of every SIMD is in its M section and its partner in its V section: the matrix pipe and
+// the vector ALU of a SIMD work at the same time BY CONSTRUCTION.  The three-waves-per-SIMD kernel above relies on waves of
+// independent workgroups happening to be out of phase, with one vmcnt(0) + barrier per tile, and measured 42 % matrix-pipe
+// busy with the vector ALU 53 % busy (profiles/r02_pmc_attention.md) -- each unit idle most of the time the other works.
+// K / V ring of four tiles each (64 KB of LDS, one workgroup per CU): the tile two ahead is requested in the M section of
+// tile j into the slot tile j - 2 left (its V was last read one barrier earlier), counted vmcnt(2), never 0 in the loop.
+// Arithmetic identical to k_attention_dma_bf16<3, false, true>: q in log2 units, reference through the matrix pipe, no
+// row maximum in the steady state (the row sum is the overflow detector), denominators on the VALU.
+constexpr int PP_SLOTS = 4;
+#ifndef GWW_PP_PRIO
+#define GWW_PP_PRIO 0   // 0: no priority changes; 1: the M section at priority 1; 2: waves 4 .. 7 at priority 1 throughout; 3: the V section at priority 1
+#endif
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void k_attention_pp_bf16(const unsigned short* __restrict__ qkv,
+                                                              unsigned short* __restrict__ ctx,
+                                                              float* __restrict__ lse, int T, int H, int q_tiles,
+                                                              int qt0) {
+  constexpr int TILE_BYTES = KB * DH * 2;   // 8 KB
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PP_SLOTS * TILE_BYTES];   // K ring | V ring
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* g_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool g1 = wave >= 4;
+  const unsigned nblk = gridDim.x, per = nblk >> 3;
+  const unsigned wid = blockIdx.x < 8 * per ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;   // XCD-aware order
+  const int qt = qt0 + wid % q_tiles;
+  const int bh = wid / q_tiles;
+  const int b = bh / H, h = bh - b * H;
+  const int d = H * DH;
+  const long row_stride = 3L * d;
+  const unsigned short* base = qkv + (long)b * T * row_stride;
+  const unsigned short* qp = base + h * DH;
+  const unsigned short* kp = base + d + h * DH;
+  const unsigned short* vp = base + 2 * d + h * DH;
+  const int r = lane & 31, hh = lane >> 5;
+  const int q_row = qt * 256 + wave * 32 + r;
+  const int q_ld = q_row < T ? q_row : T - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + (long)q_ld * row_stride + 16 * s + 8 * hh);
+
+  // ---- LDS-DMA: a tile is 8 pieces of 8 rows; wave w requests piece w of K and of V.  Lane l lands at (row l >> 3,
+  // 16-byte position l & 7), which must hold the chunk the swizzled reads expect there
+  const int n_kt = (T + KB - 1) / KB;
+  const bool ragged = (T % KB) != 0;
+  const int drow = 8 * wave + (lane >> 3), dpos = lane & 7;
+  const unsigned koff = (unsigned)(drow * (int)row_stride * 2 + ((dpos ^ ((drow >> 1) & 7)) << 4));
+  const unsigned voff = (unsigned)(drow * (int)row_stride * 2 + ((dpos ^ (((drow >> 1) & 1) << 2)) << 4));
+  auto dma = [&](int kt) {
+    const char* kb = reinterpret_cast<const char*>(kp + (long)kt * KB * row_stride);   // wave-uniform
+    const char* vb = reinterpret_cast<const char*>(vp + (long)kt * KB * row_stride);
+    unsigned char* dk = lds + (kt & (PP_SLOTS - 1)) * TILE_BYTES + wave * 1024;
+    unsigned char* dv = dk + PP_SLOTS * TILE_BYTES;
+    if (kt != n_kt - 1 || !ragged) {
+      __builtin_amdgcn_global_load_lds((g_ptr)(kb + koff), (lds_ptr)dk, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((g_ptr)(vb + voff), (lds_ptr)dv, 16, 0, 0);
+    } else {   // ragged last tile: rows past T - 1 read row T - 1 (masked afterwards; never past the tensor)
+      const int last_row = T - 1 - kt * KB;
+      const int rc = drow < last_row ? drow : last_row;
+      const unsigned ko = (unsigned)(rc * (int)row_stride * 2 + ((dpos ^ ((drow >> 1) & 7)) << 4));
+      const unsigned vo = (unsigned)(rc * (int)row_stride * 2 + ((dpos ^ (((drow >> 1) & 1) << 2)) << 4));
+      __builtin_amdgcn_global_load_lds((g_ptr)(kb + ko), (lds_ptr)dk, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((g_ptr)(vb + vo), (lds_ptr)dv, 16, 0, 0);
+    }
+  };
+
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+  const int tr_colbyte = (((lane & 31) >> 4) * 16 + 4 * tr_p) * 2;
+  const unsigned char* kbase[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) kbase[s] = lds + k_off(r, 2 * s + hh);
+  const unsigned char* vbase[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) vbase[n] = lds + PP_SLOTS * TILE_BYTES + v_off(4 * hh + tr_q, 64 * n + tr_colbyte);
+
+  f32x16 ot[2], st[2];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { ot[0][j] = 0.f; ot[1][j] = 0.f; }
+  bf16x8 ones, mref, pf[2][2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ones[j] = (__bf16)1.0f; mref[j] = (__bf16)0.0f; }
+  float l_run = 0.f, m_run = 0.f;
+  typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+
+  // S(kt) from the K tile in slot SLOT
+  auto scores = [&](auto slot_c, auto first_c) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    constexpr bool FIRST = decltype(first_c)::value;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f32x16 z;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) z[j] = 0.f;
+      if constexpr (FIRST) st[g] = z;
+      else st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, mref, z, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase[s] + SLOT * TILE_BYTES + g * (32 * 128));
+        st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[g], 0, 0, 0);
+      }
+    }
+  };
+  // O += V(slot)^T P^T with the probabilities of the tile before (pf).  The transposed fragment reads are inline asm: through
+  // the intrinsic hipcc cannot tell them from the LDS-DMA destinations and puts s_waitcnt vmcnt(0) in front of the first
+  // one -- a drain of the ring in every M section.  All sixteen go out first (ahead of the score MFMAs), one lgkmcnt(0) that
+  // names the fragments as its operands stands between them and the MFMAs that read them.
+  u32x2 vfr[2][2][2][2];   // [g][s][n][lo / hi half]
+  auto pv_reads = [&](int slot) {   // (not a generic lambda: hipcc rejects asm operands that name captured arrays in those)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const unsigned va = (unsigned)(unsigned long long)(lds_ptr)const_cast<unsigned char*>(vbase[n]) + slot * TILE_BYTES;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vfr[g][s][n][0]) : "v"(va), "n"((32 * g + 16 * s) * 128));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vfr[g][s][n][1]) : "v"(va), "n"((32 * g + 16 * s + 8) * 128));
+        }
+    }
+  };
+  auto pv_mfma = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vfr[0][0][0][0]), "+v"(vfr[0][0][0][1]), "+v"(vfr[0][0][1][0]), "+v"(vfr[0][0][1][1]),
+                   "+v"(vfr[0][1][0][0]), "+v"(vfr[0][1][0][1]), "+v"(vfr[0][1][1][0]), "+v"(vfr[0][1][1][1]),
+                   "+v"(vfr[1][0][0][0]), "+v"(vfr[1][0][0][1]), "+v"(vfr[1][0][1][0]), "+v"(vfr[1][0][1][1]),
+                   "+v"(vfr[1][1][0][0]), "+v"(vfr[1][1][0][1]), "+v"(vfr[1][1][1][0]), "+v"(vfr[1][1][1][1]));
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const u32x4 v4 = {vfr[g][s][n][0][0], vfr[g][s][n][0][1], vfr[g][s][n][1][0], vfr[g][s][n][1][1]};
+          ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v4), pf[g][s], ot[n], 0, 0, 0);
+        }
+  };
+  // exact row maximum of the tile (both key halves), then move the reference
+  auto rebase = [&](auto first_c) {
+    constexpr bool FIRST = decltype(first_c)::value;
+    float tmax = st[0][0];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tmax = fmaxf(tmax, st[g][j]);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+      tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float want = m_run + (FIRST ? tmax : fmaxf(tmax, 0.f));
+    const __bf16 hi = (__bf16)(-want);
+    const __bf16 lo = (__bf16)(-want - (float)hi);
+    const float m_new = -((float)hi + (float)lo);
+    const float dm = m_new - m_run;
+    const float alpha = __builtin_amdgcn_exp2f(-dm);
+    m_run = m_new;
+    if constexpr (!FIRST) l_run *= alpha;
+    mref[0] = hh == 0 ? hi : (__bf16)0.0f;
+    mref[1] = hh == 0 ? lo : (__bf16)0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if constexpr (!FIRST) {
+        ot[0][j] *= alpha;
+        ot[1][j] *= alpha;
+      }
+      st[0][j] -= dm;
+      st[1][j] -= dm;
+    }
+  };
+  float ps = 0.f;
+  auto exps = [&]() {
+    ps = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        st[g][j] = __builtin_amdgcn_exp2f(st[g][j]);
+        ps += st[g][j];
+      }
+  };
+
+  // ---- one tile = M section | barrier | V section | barrier
+  auto tile = [&](int kt, auto slot_c, auto first_c, auto masked_c) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    constexpr bool FIRST = decltype(first_c)::value, MASKED = decltype(masked_c)::value;
+    // M section: matrix pipe only (+ the request of the tile two ahead)
+    if (GWW_PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    if constexpr (!FIRST) pv_reads((SLOT + PP_SLOTS - 1) & (PP_SLOTS - 1));
+    scores(slot_c, first_c);
+    if constexpr (!FIRST) pv_mfma();
+    if (kt + 2 < n_kt) {
+      dma(kt + 2);
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // tile kt + 1 landed (this wave's pieces); kt + 2 in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (GWW_PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // V section: vector ALU only
+    if (GWW_PP_PRIO == 3) __builtin_amdgcn_s_setprio(1);
+    if constexpr (MASKED) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int key = kt * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
+          if (key >= T) st[g][j] = -INFINITY;
+        }
+    }
+    if constexpr (FIRST) rebase(first_c);
+    exps();
+    if constexpr (!FIRST) {
+      // 2^(8 log2 e) = e^8 = 2981: one probability above it, or an inf, lifts the half-row sum over the trigger
+      if (__builtin_amdgcn_ballot_w64(!(ps <= 2981.0f)) != 0) {   // wave-uniform, rare: exact maximum, re-based O, l, reference
+        scores(slot_c, first_c);
+        if constexpr (MASKED) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const int key = kt * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
+              if (key >= T) st[g][j] = -INFINITY;
+            }
+        }
+        rebase(first_c);
+        exps();
+      }
+    }
+    l_run += ps;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) pf[g][s] = cvt8(st[g], 8 * s);
+    if (GWW_PP_PRIO == 3) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using Yes = std::true_type;
+  using No = std::false_type;
+  auto tile_rt = [&](int kt, bool masked) {   // slot by the tile number (the remainder of the unrolled loop)
+    switch (kt & 3) {
+      case 0: if (masked) tile(kt, std::integral_constant<int, 0>{}, No{}, Yes{}); else tile(kt, std::integral_constant<int, 0>{}, No{}, No{}); break;
+      case 1: if (masked) tile(kt, std::integral_constant<int, 1>{}, No{}, Yes{}); else tile(kt, std::integral_constant<int, 1>{}, No{}, No{}); break;
+      case 2: if (masked) tile(kt, std::integral_constant<int, 2>{}, No{}, Yes{}); else tile(kt, std::integral_constant<int, 2>{}, No{}, No{}); break;
+      default: if (masked) tile(kt, std::integral_constant<int, 3>{}, No{}, Yes{}); else tile(kt, std::integral_constant<int, 3>{}, No{}, No{}); break;
+    }
+  };
+
+  dma(0);
+  if (n_kt > 1) {
+    dma(1);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (g1) __builtin_amdgcn_s_barrier();   // the trailing group: one barrier behind
+  if (GWW_PP_PRIO == 2 && g1) __builtin_amdgcn_s_setprio(1);   // static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+  if (n_kt == 1 && ragged) tile(0, std::integral_constant<int, 0>{}, Yes{}, Yes{});
+  else tile(0, std::integral_constant<int, 0>{}, Yes{}, No{});
+  {
+    int kt = 1;
+    for (; kt + 4 <= n_kt - 1; kt += 4) {   // whole groups of four full tiles, slots 1 2 3 0 (kt = 1 mod 4)
+      tile(kt, std::integral_constant<int, 1>{}, No{}, No{});
+      tile(kt + 1, std::integral_constant<int, 2>{}, No{}, No{});
+      tile(kt + 2, std::integral_constant<int, 3>{}, No{}, No{});
+      tile(kt + 3, std::integral_constant<int, 0>{}, No{}, No{});
+    }
+    for (; kt < n_kt; ++kt) tile_rt(kt, ragged && kt == n_kt - 1);
+  }
+  // the last tile's P V (the M section of a tile that does not exist)
+  pv_reads((n_kt - 1) & 3);
+  pv_mfma();
+  if (!g1) __builtin_amdgcn_s_barrier();   // the leading group: the barrier its partner is one behind with
+
+  float l_tot;
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  const float inv = 1.0f / l_tot;
+  if (lse && q_row < T && hh == 0)
+    lse[((long)b * H + h) * T + q_row] = (m_run + __log2f(l_tot)) * 0.69314718055994530942f;
+  {
+    unsigned short* orow = ctx + ((long)b * T + q_row) * d + h * DH;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        const int c0 = 2 * cp, c1 = 2 * cp + 1;
+        const unsigned a0 = pack2bf(ot[n][4 * c0] * inv, ot[n][4 * c0 + 1] * inv), a1 = pack2bf(ot[n][4 * c0 + 2] * inv, ot[n][4 * c0 + 3] * inv);
+        const unsigned b0 = pack2bf(ot[n][4 * c1] * inv, ot[n][4 * c1 + 1] * inv), b1 = pack2bf(ot[n][4 * c1 + 2] * inv, ot[n][4 * c1 + 3] * inv);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+        if (q_row < T) *reinterpret_cast<u32x4*>(orow + 32 * n + 8 * (hh ? c1 : c0)) = o;
+      }
+  }
+}
+
 // last_tile_only: compute only the query tile that holds token T - 1 (the other rows of ctx are left untouched) --
 // the pooled forward needs nothing else of the last layer's attention.
 // q_log2: q was projected with log2(e) / 8 instead of 1 / 8 (every bf16 q panel of the encoder is packed that way unless
@@ -832,15 +1143,19 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
   GWW_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)ctx) & 15) == 0, "attention_bf16: 16-byte alignment");
   if (B == 0) return GWW_OK;
   const int nw_env = getenv("GWW_ATT_WAVES") ? atoi(getenv("GWW_ATT_WAVES")) : 0;   // tuning aid (natural-q kernel): 4 or 8
-  const int nw = (nw_env == 8 && !q_log2) ? 8 : 4;
+  const int var_env = getenv("GWW_ATT_VAR") ? atoi(getenv("GWW_ATT_VAR")) : 7;     // read per call: in-process A/B
+  const bool pp = q_log2 && var_env >= 8;   // the two-waves-per-SIMD ping-pong kernel: 256 query rows per workgroup
+  const int nw = ((nw_env == 8 && !q_log2) || pp) ? 8 : 4;
   const int all_tiles = (T + nw * 32 - 1) / (nw * 32);
   const int q_tiles = last_tile_only ? 1 : all_tiles, qt0 = last_tile_only ? all_tiles - 1 : 0;
   const long blocks = (long)q_tiles * B * H;
   GWW_REQUIRE(blocks < 2147483647L, "attention_bf16: grid too large");
   const unsigned short* in = (const unsigned short*)qkv;
   unsigned short* out = (unsigned short*)ctx;
-  if (q_log2) {
-    const int var = getenv("GWW_ATT_VAR") ? atoi(getenv("GWW_ATT_VAR")) & 7 : 7;   // read per call: in-process A/B
+  if (pp) {
+    hipLaunchKernelGGL((k_attention_pp_bf16<0>), dim3((unsigned)blocks), dim3(512), 0, s, in, out, lse, T, H, q_tiles, qt0);
+  } else if (q_log2) {
+    const int var = var_env & 7;
 #define GWW_L2(VV) hipLaunchKernelGGL((k_attention_l2_bf16<4, VV>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0)
 #define GWW_DMA(MW, MS, NM) hipLaunchKernelGGL((k_attention_dma_bf16<MW, MS, NM>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0)
     switch (var) {
