@@ -904,6 +904,7 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp_bf16(const unsigned sho
   float l_run = 0.f, m_run = 0.f;
   typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
 
+  ASTAMP_DECL
   // S(kt) from the K tile in slot SLOT
   auto scores = [&](auto slot_c, auto first_c) {
     constexpr int SLOT = decltype(slot_c)::value;
@@ -956,6 +957,60 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp_bf16(const unsigned sho
           ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v4), pf[g][s], ot[n], 0, 0, 0);
         }
   };
+  // ---- the M section of a steady-state tile with every instruction PLACED (inline asm, program order = issue order): left to
+  // hipcc the section read two K fragments, waited lgkmcnt(0), issued one MFMA, read the next two ... -- the LDS latency in
+  // front of every MFMA: 1 090 ticks per tile where the 18 MFMAs need 650 (tools/stamp_att.py).  Here: the eight K reads and
+  // the first eight V reads go out back to back, the score MFMAs start as soon as the K fragments are in (the second half of
+  // the V reads rides behind the first score MFMAs), the P V MFMAs follow without a gap.
+  auto m_section = [&](int kslot, int vslot) {   // (not a generic lambda: asm operands name captured arrays)
+    u32x4 kfr[2][4];
+    unsigned ka[4], va[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ka[i] = (unsigned)(unsigned long long)(lds_ptr)const_cast<unsigned char*>(kbase[i]) + kslot * TILE_BYTES;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) va[n] = (unsigned)(unsigned long long)(lds_ptr)const_cast<unsigned char*>(vbase[n]) + vslot * TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(kfr[0][i]) : "v"(ka[i]));
+      asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(kfr[1][i]) : "v"(ka[i]));
+    }
+#define GWW_PP_VREAD(G, S, N)                                                                                                        \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vfr[G][S][N][0]) : "v"(va[N]), "n"((32 * G + 16 * S) * 128));         \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vfr[G][S][N][1]) : "v"(va[N]), "n"((32 * G + 16 * S + 8) * 128));
+    GWW_PP_VREAD(0, 0, 0) GWW_PP_VREAD(0, 0, 1) GWW_PP_VREAD(0, 1, 0) GWW_PP_VREAD(0, 1, 1)
+    // the K fragments (the eight oldest reads) are in; the eight V reads behind them may still fly
+    asm volatile("s_waitcnt lgkmcnt(8)"
+                 : "+v"(kfr[0][0]), "+v"(kfr[0][1]), "+v"(kfr[0][2]), "+v"(kfr[0][3]), "+v"(kfr[1][0]), "+v"(kfr[1][1]),
+                   "+v"(kfr[1][2]), "+v"(kfr[1][3]));
+#define GWW_PP_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+    // (hipcc may materialise `ones` / `mref` right in front: a VALU write of an MFMA source needs two wait states)
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(st[0]) : "v"(ones), "v"(mref));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(st[1]) : "v"(ones), "v"(mref));
+    GWW_PP_MFMA(st[0], kfr[0][0], qf[0]);
+    GWW_PP_MFMA(st[1], kfr[1][0], qf[0]);
+    GWW_PP_VREAD(1, 0, 0) GWW_PP_VREAD(1, 0, 1) GWW_PP_VREAD(1, 1, 0) GWW_PP_VREAD(1, 1, 1)
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      GWW_PP_MFMA(st[0], kfr[0][i], qf[i]);
+      GWW_PP_MFMA(st[1], kfr[1][i], qf[i]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vfr[0][0][0][0]), "+v"(vfr[0][0][0][1]), "+v"(vfr[0][0][1][0]), "+v"(vfr[0][0][1][1]),
+                   "+v"(vfr[0][1][0][0]), "+v"(vfr[0][1][0][1]), "+v"(vfr[0][1][1][0]), "+v"(vfr[0][1][1][1]),
+                   "+v"(vfr[1][0][0][0]), "+v"(vfr[1][0][0][1]), "+v"(vfr[1][0][1][0]), "+v"(vfr[1][0][1][1]),
+                   "+v"(vfr[1][1][0][0]), "+v"(vfr[1][1][0][1]), "+v"(vfr[1][1][1][0]), "+v"(vfr[1][1][1][1]));
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const u32x4 v4 = {vfr[g][sk][n][0][0], vfr[g][sk][n][0][1], vfr[g][sk][n][1][0], vfr[g][sk][n][1][1]};
+          GWW_PP_MFMA(ot[n], v4, pf[g][sk]);
+        }
+#undef GWW_PP_MFMA
+#undef GWW_PP_VREAD
+  };
   // exact row maximum of the tile (both key halves), then move the reference
   auto rebase = [&](auto first_c) {
     constexpr bool FIRST = decltype(first_c)::value;
@@ -1005,10 +1060,10 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp_bf16(const unsigned sho
     constexpr int SLOT = decltype(slot_c)::value;
     constexpr bool FIRST = decltype(first_c)::value, MASKED = decltype(masked_c)::value;
     // M section: matrix pipe only (+ the request of the tile two ahead)
+    ASTAMP(5);
     if (GWW_PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-    if constexpr (!FIRST) pv_reads((SLOT + PP_SLOTS - 1) & (PP_SLOTS - 1));
-    scores(slot_c, first_c);
-    if constexpr (!FIRST) pv_mfma();
+    if constexpr (FIRST) scores(slot_c, first_c);
+    else m_section(SLOT, (SLOT + PP_SLOTS - 1) & (PP_SLOTS - 1));
     if (kt + 2 < n_kt) {
       dma(kt + 2);
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // tile kt + 1 landed (this wave's pieces); kt + 2 in flight
@@ -1017,8 +1072,10 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp_bf16(const unsigned sho
     }
     if (GWW_PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    if (g1) { ASTAMP(2); } else { ASTAMP(0); }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    ASTAMP(4);
     // V section: vector ALU only
     if (GWW_PP_PRIO == 3) __builtin_amdgcn_s_setprio(1);
     if constexpr (MASKED) {
@@ -1056,6 +1113,7 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp_bf16(const unsigned sho
       for (int s = 0; s < 2; ++s) pf[g][s] = cvt8(st[g], 8 * s);
     if (GWW_PP_PRIO == 3) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    if (g1) { ASTAMP(3); } else { ASTAMP(1); }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -1096,6 +1154,8 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp_bf16(const unsigned sho
   pv_reads((n_kt - 1) & 3);
   pv_mfma();
   if (!g1) __builtin_amdgcn_s_barrier();   // the leading group: the barrier its partner is one behind with
+  ASTAMP(6);
+  ASTAMP_FLUSH
 
   float l_tot;
   {
