@@ -89,3 +89,35 @@ def test_spill_audit_flags_a_scratch_access_inside_a_loop_and_a_count_over_its_c
     assert rc == 1 and "FAIL" in out
     rc, out = run(flat + loop, "kernel=2")    # within the ceiling, but inside a loop
     assert rc == 1 and "1 scratch accesses inside loops" in out
+
+
+# ---- tools/audit_asm_preload.py (gemm_v4.hip: the fp32 residual requested straight into the accumulator registers)
+_PRE_LOAD = _asm("global_load_dwordx4 v[116:119], v[100:101], off")
+_PRE_WAIT = _asm("s_waitcnt vmcnt(8)")
+
+
+def test_asm_preload_audit_accepts_load_wait_mfma(tmp_path):
+    body = _PRE_LOAD + "\tv_add_f32_e32 v1, v2, v3\n" + _PRE_WAIT + "\tv_mfma_f32_16x16x32_bf16 v[120:123], v[8:11], v[12:15], v[116:119]\n"
+    rc, out = _run("audit_asm_preload.py", body, tmp_path)
+    assert rc == 0 and "1 asm loads checked, 0 problems" in out
+
+
+def test_asm_preload_audit_flags_a_copy_an_unwaited_mfma_and_a_spill(tmp_path):
+    # a register copy of the destination before the data can have landed
+    rc, out = _run("audit_asm_preload.py", _PRE_LOAD + "\tv_mov_b64_e32 v[118:119], v[66:67]\n" + _PRE_WAIT, tmp_path)
+    assert rc == 1 and "AUDIT FAIL" in out
+    # the accumulating MFMA without any vmcnt wait in between
+    rc, out = _run("audit_asm_preload.py", _PRE_LOAD + "\tv_mfma_f32_16x16x32_bf16 v[116:119], v[8:11], v[12:15], v[116:119]\n", tmp_path)
+    assert rc == 1 and "waited=False" in out
+    # a spill anywhere in the kernel (it would sit uncounted in the hand-counted vmcnt queue)
+    body = "\tscratch_store_dwordx2 off, v[8:9], off\n" + _PRE_LOAD + _PRE_WAIT + "\tv_mfma_f32_16x16x32_bf16 v[116:119], v[8:11], v[12:15], v[116:119]\n"
+    rc, out = _run("audit_asm_preload.py", body, tmp_path)
+    assert rc == 1 and "scratch access" in out
+
+
+def test_asm_preload_audit_follows_an_unconditional_branch_over_the_else_block(tmp_path):
+    # then-block: the loads; else-block (behind s_branch): zeroing moves of the same registers -- not a use of the loaded data
+    body = (_PRE_LOAD + "\ts_branch .LBB0_9\n.LBB0_8:\n\tv_mov_b64_e32 v[118:119], v[66:67]\n.LBB0_9:\n" + _PRE_WAIT +
+            "\tv_mfma_f32_16x16x32_bf16 v[120:123], v[8:11], v[12:15], v[116:119]\n")
+    rc, out = _run("audit_asm_preload.py", body, tmp_path)
+    assert rc == 0, out
