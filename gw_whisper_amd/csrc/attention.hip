@@ -831,8 +831,8 @@ constexpr int PP_SLOTS = 4;
 #ifndef GWW_PP_PRIO
 #define GWW_PP_PRIO 0   // 0: no priority changes; 1: the M section at priority 1; 2: waves 4 .. 7 at priority 1 throughout; 3: the V section at priority 1
 #endif
-template <int DUMMY>
-__global__ __launch_bounds__(512, 1) void k_attention_pp_bf16(const unsigned short* __restrict__ qkv,
+template <int MODE>
+__global__ __launch_bounds__(MODE == 1 ? 256 : 512, 1) void k_attention_pp_bf16(const unsigned short* __restrict__ qkv,
                                                               unsigned short* __restrict__ ctx,
                                                               float* __restrict__ lse, int T, int H, int q_tiles,
                                                               int qt0) {
@@ -843,6 +843,9 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp_bf16(const unsigned sho
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool g1 = wave >= 4;
+  // MODE 1 (interleaved): FOUR waves, one per SIMD, each with the whole 512-register file (two score sets + both fragment
+  // sets + O do not fit 256 registers: 49 spilled, and a spill is an uncounted entry of the in-order vmcnt queue)
+  constexpr int NWV = MODE == 1 ? 4 : 8, PPW = 8 / NWV;   // waves per workgroup, LDS-DMA pieces per wave, operand and tile
   const unsigned nblk = gridDim.x, per = nblk >> 3;
   const unsigned wid = blockIdx.x < 8 * per ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;   // XCD-aware order
   const int qt = qt0 + wid % q_tiles;
@@ -855,7 +858,7 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp_bf16(const unsigned sho
   const unsigned short* kp = base + d + h * DH;
   const unsigned short* vp = base + 2 * d + h * DH;
   const int r = lane & 31, hh = lane >> 5;
-  const int q_row = qt * 256 + wave * 32 + r;
+  const int q_row = qt * (NWV * 32) + wave * 32 + r;
   const int q_ld = q_row < T ? q_row : T - 1;
   bf16x8 qf[4];
 #pragma unroll
@@ -865,24 +868,36 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp_bf16(const unsigned sho
   // 16-byte position l & 7), which must hold the chunk the swizzled reads expect there
   const int n_kt = (T + KB - 1) / KB;
   const bool ragged = (T % KB) != 0;
-  const int drow = 8 * wave + (lane >> 3), dpos = lane & 7;
-  const unsigned koff = (unsigned)(drow * (int)row_stride * 2 + ((dpos ^ ((drow >> 1) & 7)) << 4));
-  const unsigned voff = (unsigned)(drow * (int)row_stride * 2 + ((dpos ^ (((drow >> 1) & 1) << 2)) << 4));
+  const int dpos = lane & 7;
+  int drow[PPW];
+  unsigned koff[PPW], voff[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    drow[j] = 8 * (wave + NWV * j) + (lane >> 3);
+    koff[j] = (unsigned)(drow[j] * (int)row_stride * 2 + ((dpos ^ ((drow[j] >> 1) & 7)) << 4));
+    voff[j] = (unsigned)(drow[j] * (int)row_stride * 2 + ((dpos ^ (((drow[j] >> 1) & 1) << 2)) << 4));
+  }
   auto dma = [&](int kt) {
     const char* kb = reinterpret_cast<const char*>(kp + (long)kt * KB * row_stride);   // wave-uniform
     const char* vb = reinterpret_cast<const char*>(vp + (long)kt * KB * row_stride);
-    unsigned char* dk = lds + (kt & (PP_SLOTS - 1)) * TILE_BYTES + wave * 1024;
-    unsigned char* dv = dk + PP_SLOTS * TILE_BYTES;
     if (kt != n_kt - 1 || !ragged) {
-      __builtin_amdgcn_global_load_lds((g_ptr)(kb + koff), (lds_ptr)dk, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((g_ptr)(vb + voff), (lds_ptr)dv, 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) {
+        unsigned char* dk = lds + (kt & (PP_SLOTS - 1)) * TILE_BYTES + (wave + NWV * j) * 1024;
+        __builtin_amdgcn_global_load_lds((g_ptr)(kb + koff[j]), (lds_ptr)dk, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((g_ptr)(vb + voff[j]), (lds_ptr)(dk + PP_SLOTS * TILE_BYTES), 16, 0, 0);
+      }
     } else {   // ragged last tile: rows past T - 1 read row T - 1 (masked afterwards; never past the tensor)
       const int last_row = T - 1 - kt * KB;
-      const int rc = drow < last_row ? drow : last_row;
-      const unsigned ko = (unsigned)(rc * (int)row_stride * 2 + ((dpos ^ ((drow >> 1) & 7)) << 4));
-      const unsigned vo = (unsigned)(rc * (int)row_stride * 2 + ((dpos ^ (((drow >> 1) & 1) << 2)) << 4));
-      __builtin_amdgcn_global_load_lds((g_ptr)(kb + ko), (lds_ptr)dk, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((g_ptr)(vb + vo), (lds_ptr)dv, 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) {
+        unsigned char* dk = lds + (kt & (PP_SLOTS - 1)) * TILE_BYTES + (wave + NWV * j) * 1024;
+        const int rc = drow[j] < last_row ? drow[j] : last_row;
+        const unsigned ko = (unsigned)(rc * (int)row_stride * 2 + ((dpos ^ ((drow[j] >> 1) & 7)) << 4));
+        const unsigned vo = (unsigned)(rc * (int)row_stride * 2 + ((dpos ^ (((drow[j] >> 1) & 1) << 2)) << 4));
+        __builtin_amdgcn_global_load_lds((g_ptr)(kb + ko), (lds_ptr)dk, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((g_ptr)(vb + vo), (lds_ptr)(dk + PP_SLOTS * TILE_BYTES), 16, 0, 0);
+      }
     }
   };
 
@@ -1055,6 +1070,233 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp_bf16(const unsigned sho
       }
   };
 
+  if constexpr (MODE == 1) {
+    // ================= interleaved form (GWW_ATT_VAR = 9): no wave-against-wave alternation.  What the ping-pong form showed
+    // is that the MFMAs of one wave and the VALU stream of its partner do NOT share a SIMD's vector-issue port well (the
+    // partner's section is simply appended: profiles/r03_attention_pp.md), while ONE wave's own VALU instructions do run in
+    // the shadow of its own MFMAs (the fused MLP block's GELU: 34 cycles per MFMA with eight VALU operations behind each).
+    // So every wave software-pipelines its own tiles: iteration kt issues S(kt) = K(kt) Q^T -- ten asm MFMAs in program
+    // order -- with the softmax of tile kt - 1 (exp, row sum, bf16 convert) cut into ten chunks placed between them, then
+    // O += V(kt-1)^T P(kt-1)^T.  Two score sets (sA, sB) alternate as "being produced" / "being exponentiated".
+    f32x16 sA[2], sB[2];
+    auto scores_into = [&](f32x16 (&sc)[2], int kslot, bool first) {   // compiler-scheduled: prologue, epilogue, rare path
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        f32x16 z;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) z[j] = 0.f;
+        if (first) sc[g] = z;
+        else sc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, mref, z, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase[i] + kslot * TILE_BYTES + g * (32 * 128));
+          sc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[i], sc[g], 0, 0, 0);
+        }
+      }
+    };
+    auto mask_tail = [&](f32x16 (&sc)[2], int kt) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int key = kt * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
+          if (key >= T) sc[g][j] = -INFINITY;
+        }
+    };
+    // exact row maximum of the tile, new reference; returns the shift of the reference (scores computed against the old one
+    // must be lowered by it)
+    auto rebase_on = [&](f32x16 (&sc)[2], bool first) -> float {
+      float tmax = sc[0][0];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tmax = fmaxf(tmax, sc[g][j]);
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+      const float want = m_run + (first ? tmax : fmaxf(tmax, 0.f));
+      const __bf16 hi = (__bf16)(-want);
+      const __bf16 lo = (__bf16)(-want - (float)hi);
+      const float m_new = -((float)hi + (float)lo);
+      const float dm = m_new - m_run;
+      const float alpha = __builtin_amdgcn_exp2f(-dm);
+      m_run = m_new;
+      if (!first) l_run *= alpha;
+      mref[0] = hh == 0 ? hi : (__bf16)0.0f;
+      mref[1] = hh == 0 ? lo : (__bf16)0.0f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (!first) {
+          ot[0][j] *= alpha;
+          ot[1][j] *= alpha;
+        }
+        sc[0][j] -= dm;
+        sc[1][j] -= dm;
+      }
+      return dm;
+    };
+    auto exps_on = [&](f32x16 (&sc)[2]) {
+      ps = 0.f;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          sc[g][j] = __builtin_amdgcn_exp2f(sc[g][j]);
+          ps += sc[g][j];
+        }
+    };
+    auto cvt_all = [&](f32x16 (&sc)[2]) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk) pf[g][sk] = cvt8(sc[g], 8 * sk);
+    };
+    // one steady-state iteration: cur <- S(kt) (asm MFMAs), prv = S(kt - 1) -> probabilities (chunks between the MFMAs),
+    // then O += V(kt - 1)^T P(kt - 1)^T
+    auto il_iter = [&](f32x16 (&prv)[2], f32x16 (&cur)[2], int kt) {
+      const int kslot = kt & (PP_SLOTS - 1), vslot = (kt - 1) & (PP_SLOTS - 1);
+      u32x4 kfr[2][4];
+      unsigned ka[4], va[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ka[i] = (unsigned)(unsigned long long)(lds_ptr)const_cast<unsigned char*>(kbase[i]) + kslot * TILE_BYTES;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) va[n] = (unsigned)(unsigned long long)(lds_ptr)const_cast<unsigned char*>(vbase[n]) + vslot * TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kfr[0][i]) : "v"(ka[i]));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(kfr[1][i]) : "v"(ka[i]));
+      }
+#define GWW_IL_VREAD(G, S, N)                                                                                                       \
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vfr[G][S][N][0]) : "v"(va[N]), "n"((32 * G + 16 * S) * 128));       \
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vfr[G][S][N][1]) : "v"(va[N]), "n"((32 * G + 16 * S + 8) * 128));
+      // (the V fragments are requested later, into the registers the K fragments leave: sixteen more live registers spill)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(kfr[0][0]), "+v"(kfr[0][1]), "+v"(kfr[0][2]), "+v"(kfr[0][3]), "+v"(kfr[1][0]), "+v"(kfr[1][1]),
+                     "+v"(kfr[1][2]), "+v"(kfr[1][3]));
+      ps = 0.f;
+      // chunk C of the softmax of tile kt - 1: exponentials and row sum of scores [32 C / 10, 32 (C + 1) / 10), a bf16 convert
+      // where eight neighbours are complete; the empty asm pins it between the MFMA before and the MFMA behind it (it names
+      // what the chunk produced AND what the next chunk will read, so hipcc can move neither across it)
+#define GWW_IL_CHUNK(C)                                                                                       \
+      {                                                                                                       \
+        _Pragma("unroll") for (int idx = (C) * 32 / 10; idx < ((C) + 1) * 32 / 10; ++idx) {                   \
+          float tv = prv[idx >> 4][idx & 15];                                                                 \
+          tv = __builtin_amdgcn_exp2f(tv);                                                                    \
+          ps += tv;                                                                                           \
+          prv[idx >> 4][idx & 15] = tv;                                                                       \
+        }                                                                                                     \
+        if ((C) == 3) pf[0][0] = cvt8(prv[0], 0);                                                             \
+        if ((C) == 5) pf[0][1] = cvt8(prv[0], 8);                                                             \
+        if ((C) == 8) pf[1][0] = cvt8(prv[1], 0);                                                             \
+        if ((C) == 9) pf[1][1] = cvt8(prv[1], 8);                                                             \
+        asm volatile("" : "+v"(ps), "+v"(prv[0]), "+v"(prv[1]), "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[1][0]), "+v"(pf[1][1])); \
+      }
+// (s_nop 1 in front of every asm MFMA: above 256 registers hipcc parks values in AGPRs and fetches them with v_accvgpr_read
+// right in front of the statement -- a VALU write of an MFMA source needs two wait states; tools/audit_asm_mfma.py)
+#define GWW_IL_MFMA(ACC, A, B) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define GWW_IL_MFMA_O(ACC, A, B) GWW_IL_MFMA(ACC, A, B)
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(cur[0]) : "v"(ones), "v"(mref));
+      GWW_IL_CHUNK(0)
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(cur[1]) : "v"(ones), "v"(mref));
+      GWW_IL_CHUNK(1)
+      GWW_IL_MFMA(cur[0], kfr[0][0], qf[0]);
+      GWW_IL_CHUNK(2)
+      GWW_IL_MFMA(cur[1], kfr[1][0], qf[0]);
+      GWW_IL_CHUNK(3)
+      GWW_IL_MFMA(cur[0], kfr[0][1], qf[1]);
+      GWW_IL_CHUNK(4)
+      GWW_IL_MFMA(cur[1], kfr[1][1], qf[1]);
+      GWW_IL_VREAD(0, 0, 0) GWW_IL_VREAD(0, 0, 1) GWW_IL_VREAD(0, 1, 0) GWW_IL_VREAD(0, 1, 1)
+      GWW_IL_CHUNK(5)
+      GWW_IL_MFMA(cur[0], kfr[0][2], qf[2]);
+      GWW_IL_CHUNK(6)
+      GWW_IL_MFMA(cur[1], kfr[1][2], qf[2]);
+      GWW_IL_CHUNK(7)
+      GWW_IL_MFMA(cur[0], kfr[0][3], qf[3]);
+      GWW_IL_CHUNK(8)
+      GWW_IL_MFMA(cur[1], kfr[1][3], qf[3]);
+      GWW_IL_VREAD(1, 0, 0) GWW_IL_VREAD(1, 0, 1) GWW_IL_VREAD(1, 1, 0) GWW_IL_VREAD(1, 1, 1)
+      GWW_IL_CHUNK(9)
+      // 2^(8 log2 e) = e^8 = 2981: one probability above it, or an inf, lifts the half-row sum over the trigger
+      if (__builtin_amdgcn_ballot_w64(!(ps <= 2981.0f)) != 0) {   // wave-uniform, rare: exact maximum, re-based O, l, reference
+        scores_into(prv, vslot, false);
+        const float dm = rebase_on(prv, false);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { cur[0][j] -= dm; cur[1][j] -= dm; }   // S(kt) was formed against the old reference
+        exps_on(prv);
+        cvt_all(prv);
+      }
+      l_run += ps;
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(vfr[0][0][0][0]), "+v"(vfr[0][0][0][1]), "+v"(vfr[0][0][1][0]), "+v"(vfr[0][0][1][1]),
+                     "+v"(vfr[0][1][0][0]), "+v"(vfr[0][1][0][1]), "+v"(vfr[0][1][1][0]), "+v"(vfr[0][1][1][1]),
+                     "+v"(vfr[1][0][0][0]), "+v"(vfr[1][0][0][1]), "+v"(vfr[1][0][1][0]), "+v"(vfr[1][0][1][1]),
+                     "+v"(vfr[1][1][0][0]), "+v"(vfr[1][1][0][1]), "+v"(vfr[1][1][1][0]), "+v"(vfr[1][1][1][1]));
+      asm volatile("s_nop 1");   // the converts wrote MFMA sources
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const u32x4 v4 = {vfr[g][sk][n][0][0], vfr[g][sk][n][0][1], vfr[g][sk][n][1][0], vfr[g][sk][n][1][1]};
+            GWW_IL_MFMA_O(ot[n], v4, pf[g][sk]);
+          }
+#undef GWW_IL_MFMA
+#undef GWW_IL_MFMA_O
+#undef GWW_IL_CHUNK
+#undef GWW_IL_VREAD
+      if (kt + 2 < n_kt) {
+        dma(kt + 2);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile kt + 1 landed (this wave's pieces); kt + 2 in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    };
+
+    dma(0);
+    if (n_kt > 1) dma(1);
+    if (n_kt > 2) {
+      dma(2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    scores_into(sA, 0, true);
+    if (n_kt == 1 && ragged) mask_tail(sA, 0);
+    rebase_on(sA, true);
+    int kt = 1;
+    for (; kt + 1 < n_kt; kt += 2) {
+      il_iter(sA, sB, kt);
+      il_iter(sB, sA, kt + 1);
+    }
+    if (kt < n_kt) {
+      il_iter(sA, sB, kt);
+      ++kt;
+    }
+    // the last tile: its softmax and P V (scheduled by hipcc)
+    {
+      const bool last_in_b = ((n_kt - 1) & 1) != 0;   // tile t sits in sA for even t
+      auto finish = [&](f32x16 (&sc)[2]) {
+        if (ragged && n_kt > 1) mask_tail(sc, n_kt - 1);
+        exps_on(sc);
+        if (n_kt > 1 && __builtin_amdgcn_ballot_w64(!(ps <= 2981.0f)) != 0) {
+          scores_into(sc, (n_kt - 1) & (PP_SLOTS - 1), false);
+          if (ragged) mask_tail(sc, n_kt - 1);
+          rebase_on(sc, false);
+          exps_on(sc);
+        }
+        l_run += ps;
+        cvt_all(sc);
+      };
+      if (last_in_b) finish(sB); else finish(sA);
+      pv_reads((n_kt - 1) & (PP_SLOTS - 1));
+      pv_mfma();
+    }
+  } else {
   // ---- one tile = M section | barrier | V section | barrier
   auto tile = [&](int kt, auto slot_c, auto first_c, auto masked_c) {
     constexpr int SLOT = decltype(slot_c)::value;
@@ -1156,6 +1398,7 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp_bf16(const unsigned sho
   if (!g1) __builtin_amdgcn_s_barrier();   // the leading group: the barrier its partner is one behind with
   ASTAMP(6);
   ASTAMP_FLUSH
+  }   // MODE
 
   float l_tot;
   {
@@ -1205,14 +1448,16 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
   const int nw_env = getenv("GWW_ATT_WAVES") ? atoi(getenv("GWW_ATT_WAVES")) : 0;   // tuning aid (natural-q kernel): 4 or 8
   const int var_env = getenv("GWW_ATT_VAR") ? atoi(getenv("GWW_ATT_VAR")) : 7;     // read per call: in-process A/B
   const bool pp = q_log2 && var_env >= 8;   // the two-waves-per-SIMD ping-pong kernel: 256 query rows per workgroup
-  const int nw = ((nw_env == 8 && !q_log2) || pp) ? 8 : 4;
+  const int nw = ((nw_env == 8 && !q_log2) || (pp && var_env == 8)) ? 8 : 4;
   const int all_tiles = (T + nw * 32 - 1) / (nw * 32);
   const int q_tiles = last_tile_only ? 1 : all_tiles, qt0 = last_tile_only ? all_tiles - 1 : 0;
   const long blocks = (long)q_tiles * B * H;
   GWW_REQUIRE(blocks < 2147483647L, "attention_bf16: grid too large");
   const unsigned short* in = (const unsigned short*)qkv;
   unsigned short* out = (unsigned short*)ctx;
-  if (pp) {
+  if (pp && var_env >= 9) {
+    hipLaunchKernelGGL((k_attention_pp_bf16<1>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0);
+  } else if (pp) {
     hipLaunchKernelGGL((k_attention_pp_bf16<0>), dim3((unsigned)blocks), dim3(512), 0, s, in, out, lse, T, H, q_tiles, qt0);
   } else if (q_log2) {
     const int var = var_env & 7;

@@ -289,11 +289,11 @@ def _attn_ref_log2q(qkv_l2, H):
     return o.transpose(0, 2, 1, 3).reshape(B, Tn, d)
 
 
-@pytest.fixture(params=["default", "var0", "var1", "var2", "var3", "var4", "var5", "var6", "var8"])
+@pytest.fixture(params=["default", "var0", "var1", "var2", "var3", "var4", "var5", "var6", "var8", "var9"])
 def att_variant(request, monkeypatch):
     """The log2-unit-q kernels: k_attention_dma_bf16 (default = GWW_ATT_VAR 7; 4 .. 6 its variants), the
-    register-staged k_attention_l2_bf16 (0 .. 3) and the two-waves-per-SIMD k_attention_pp_bf16 (8); the launcher reads
-    GWW_ATT_VAR per call."""
+    register-staged k_attention_l2_bf16 (0 .. 3), the two-waves-per-SIMD k_attention_pp_bf16 (8) and its interleaved
+    one-wave-per-SIMD form (9); the launcher reads GWW_ATT_VAR per call."""
     v = request.param
     if v.startswith("var"):
         monkeypatch.setenv("GWW_ATT_VAR", v[-1])

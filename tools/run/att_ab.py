@@ -10,7 +10,7 @@ H = 6
 torch.manual_seed(0)
 qkv = (torch.randn(B, 1500, 3 * H * 64, device="cuda") * 0.5).bfloat16()
 arms = {"old(natural q)": (None, None, ops.attention)}
-for v in (7, 8):
+for v in (7, 8, 9):
     arms[f"l2 var{v}"] = (str(v), None, ops.attention_log2q)
 times = {k: [] for k in arms}
 def run(name):
