@@ -1174,6 +1174,7 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : 512, 1) void k_attention_pp_bf16(
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(kfr[0][0]), "+v"(kfr[0][1]), "+v"(kfr[0][2]), "+v"(kfr[0][3]), "+v"(kfr[1][0]), "+v"(kfr[1][1]),
                      "+v"(kfr[1][2]), "+v"(kfr[1][3]));
+      ASTAMP(0);
       ps = 0.f;
       // chunk C of the softmax of tile kt - 1: exponentials and row sum of scores [32 C / 10, 32 (C + 1) / 10), a bf16 convert
       // where eight neighbours are complete; the empty asm pins it between the MFMA before and the MFMA behind it (it names
@@ -1218,6 +1219,7 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : 512, 1) void k_attention_pp_bf16(
       GWW_IL_MFMA(cur[1], kfr[1][3], qf[3]);
       GWW_IL_VREAD(1, 0, 0) GWW_IL_VREAD(1, 0, 1) GWW_IL_VREAD(1, 1, 0) GWW_IL_VREAD(1, 1, 1)
       GWW_IL_CHUNK(9)
+      ASTAMP(1);
       // 2^(8 log2 e) = e^8 = 2981: one probability above it, or an inf, lifts the half-row sum over the trigger
       if (__builtin_amdgcn_ballot_w64(!(ps <= 2981.0f)) != 0) {   // wave-uniform, rare: exact maximum, re-based O, l, reference
         scores_into(prv, vslot, false);
@@ -1243,6 +1245,7 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : 512, 1) void k_attention_pp_bf16(
             const u32x4 v4 = {vfr[g][sk][n][0][0], vfr[g][sk][n][0][1], vfr[g][sk][n][1][0], vfr[g][sk][n][1][1]};
             GWW_IL_MFMA_O(ot[n], v4, pf[g][sk]);
           }
+      ASTAMP(2);
 #undef GWW_IL_MFMA
 #undef GWW_IL_MFMA_O
 #undef GWW_IL_CHUNK
@@ -1253,7 +1256,9 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : 512, 1) void k_attention_pp_bf16(
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      ASTAMP(3);
       __builtin_amdgcn_s_barrier();
+      ASTAMP(4);
     };
 
     dma(0);
@@ -1295,6 +1300,8 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : 512, 1) void k_attention_pp_bf16(
       if (last_in_b) finish(sB); else finish(sA);
       pv_reads((n_kt - 1) & (PP_SLOTS - 1));
       pv_mfma();
+      ASTAMP(6);
+      ASTAMP_FLUSH
     }
   } else {
   // ---- one tile = M section | barrier | V section | barrier

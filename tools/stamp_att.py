@@ -27,7 +27,9 @@ lib.gww_debug_stamps_att(buf, 1)
 for _ in range(3): fn()
 torch.cuda.synchronize()
 lib.gww_debug_stamps_att(buf, 1)
-if os.environ.get("GWW_ATT_VAR") == "8":
+if os.environ.get("GWW_ATT_VAR") == "9":
+    names = ["K-fragment reads + their wait", "ten score MFMAs with the softmax chunks of the tile before", "V-fragment wait + eight P V MFMAs", "LDS-DMA request + ring wait", "barrier", "-", "prologue + last tile + epilogue"]
+elif os.environ.get("GWW_ATT_VAR") == "8":
     names = ["M section, waves 0-3 (score + P V MFMAs, fragment reads, LDS-DMA request, ring wait) [x2: per wave of the group]", "V section, waves 0-3 (softmax VALU) [x2]", "M section, waves 4-7 [x2]", "V section, waves 4-7 [x2]", "barrier behind the M section", "barrier behind the V section", "prologue + last P V + epilogue"]
 else:
   names = ["prologue+epilogue", "issue next-tile global loads", "S = K Q^T (LDS reads + 8 MFMA)", "softmax (max, exp, cvt)", "O += V^T P (tr reads + 12 MFMA)", "LDS store of next tile", "barrier"]
