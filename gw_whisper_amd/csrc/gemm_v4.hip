@@ -34,6 +34,7 @@
 #include "common.h"
 #include "epilogue.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace gww {
@@ -492,16 +493,11 @@ int launch_gemm_bf16_v4(const void* A, long lda, const void* W, const float* bia
   if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID)) return -1;
   const long panels = cdiv(M, 256);
   const int tn = N / 256;
-  // column splits: a split's W slice should sit in one XCD's 4-MB L2 beside the streaming A panels (<= 1.5 MB); enough
-  // items for an even load over the CUs
-  long fit = (3L << 19) / (256L * K * 2);
-  if (fit < 1) fit = 1;
-  if (fit > 6) fit = 6;
-  int n_split = tn;
-  for (int s2 = 1; s2 <= tn; ++s2)
-    if (tn % s2 == 0 && tn / s2 <= fit && (panels * s2 >= 768 || s2 == tn)) { n_split = s2; break; }
-  const long n_items = panels * n_split;
-  GWW_REQUIRE(n_items < 2147483647L, "gemm_bf16: grid too large");
+  // column splits: a split's W slice should sit in one XCD's 4-MB L2 beside the streaming A panels (<= 1.5 MB).  Among the
+  // splits that allow it the one with the best load balance wins: the items of an XCD (an eighth of them) are dealt to
+  // its CUs round-robin and all take the same time, so the launch lasts ceil(items per XCD / CUs per XCD) item times --
+  // whisper-small's q/k/v at B = 64: 376 panels x 3 splits = 141 items per XCD on 32 CUs = 5 rounds for 4.4 (88 %),
+  // x 9 splits = 423 = 14 rounds for 13.2 (94 %)
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -510,6 +506,26 @@ int launch_gemm_bf16_v4(const void* A, long lda, const void* W, const float* bia
     GWW_HIP(hipGetDeviceProperties(&prop, dev));
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
+  long fit = (3L << 19) / (256L * K * 2);
+  if (fit < 1) fit = 1;
+  if (fit > 6) fit = 6;
+  int n_split = tn;
+  {
+    const long cu_x = n_cu >= 8 ? n_cu / 8 : 1;
+    double best = -1.0;
+    for (int s2 = 1; s2 <= tn; ++s2) {
+      if (tn % s2 != 0 || (tn / s2 > fit && s2 != tn)) continue;
+      const long per_x = cdiv(panels * s2, 8);
+      const double eff = (double)per_x / (double)(cdiv(per_x, cu_x) * cu_x);
+      if (eff > best + 0.01) { best = eff; n_split = s2; }   // ties: the fewer, longer items
+    }
+  }
+  if (const char* e = getenv("GWW_G4_NSPLIT")) {   // tuning aid: force the column split (a divisor of N / 256)
+    const int f = atoi(e);
+    if (f >= 1 && f <= tn && tn % f == 0) n_split = f;
+  }
+  const long n_items = panels * n_split;
+  GWW_REQUIRE(n_items < 2147483647L, "gemm_bf16: grid too large");
   // one block per CU at most (140 KB of LDS each); a block's k-tile stream runs through its items
   dim3 grid((unsigned)(n_items < n_cu ? n_items : n_cu)), block(512);
   const int tpi = tn / n_split;
