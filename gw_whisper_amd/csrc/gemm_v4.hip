@@ -500,11 +500,10 @@ int launch_gemm_bf16_v4(const void* A, long lda, const void* W, const float* bia
   // x 9 splits = 423 = 14 rounds for 13.2 (94 %)
   static int n_cu = 0;
   if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
+    int dev = 0, cus = 0;
     GWW_HIP(hipGetDevice(&dev));
-    GWW_HIP(hipGetDeviceProperties(&prop, dev));
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    GWW_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));   // (no stream operation: capture-safe)
+    n_cu = cus > 0 ? cus : 256;
   }
   long fit = (3L << 19) / (256L * K * 2);
   if (fit < 1) fit = 1;

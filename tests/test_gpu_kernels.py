@@ -141,6 +141,37 @@ def test_gemm_bf16(T, gww, M, N, K, epi):
         np.testing.assert_allclose(got, ref, atol=1e-5 * np.sqrt(K), rtol=2 ** -8)
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 1536, 384), (66560, 1536, 256), (2560, 3072, 128)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_v4_result_does_not_depend_on_the_column_split(T, gww, monkeypatch, M, N, K, epi):
+    """k_gemm_bf16_v4: an output element's accumulation order does not depend on how the column tiles are dealt to work
+    items, so every column split (GWW_G4_NSPLIT: 1 .. N / 256 tiles per item, i.e. one to many tiles per item, items per
+    block and residual preloads across tile AND item boundaries) must give bit-identical results -- and the fp64 product."""
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(M + N + K + epi)
+    a = T.from_numpy(_bf(rng.standard_normal((M, K)))).cuda().bfloat16()
+    w = T.from_numpy(_bf(rng.standard_normal((N, K)) / np.sqrt(K))).cuda().bfloat16()
+    bias = T.from_numpy(rng.standard_normal(N).astype(np.float32)).cuda()
+    resid = T.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda() if epi == 2 else None
+    tn = N // 256
+    outs = {}
+    for split in [s for s in range(1, tn + 1) if tn % s == 0]:
+        monkeypatch.setenv("GWW_G4_NSPLIT", str(split))
+        outs[split] = ops.gemm(a, w, bias, epilogue=epi, resid=resid)
+    monkeypatch.delenv("GWW_G4_NSPLIT")
+    auto = ops.gemm(a, w, bias, epilogue=epi, resid=resid)
+    for split, o in outs.items():
+        assert T.equal(o, auto), f"split {split} differs from the automatic split"
+    if M <= 4096:
+        ref = a.double() @ w.double().T + bias.double()
+        if epi == 1:
+            ref = T.nn.functional.gelu(ref)
+        if epi == 2:
+            ref = ref + resid.double()
+        tol = dict(atol=2e-5 * np.sqrt(K), rtol=1e-5) if epi == 2 else dict(atol=1e-5 * np.sqrt(K), rtol=2 ** -8)
+        np.testing.assert_allclose(auto.double().cpu().numpy(), ref.cpu().numpy(), **tol)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 128, 384), (1500, 1152, 384), (3000, 384, 384), (777, 1536, 384),
                                    (512, 256, 256), (300, 512, 512), (5000, 1536, 384), (6000, 1024, 512)])
 @pytest.mark.parametrize("epi", [0, 1])
