@@ -37,7 +37,7 @@ import torch  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # collected by tools/pmc_traffic.py (separate rocprofv3 --pmc passes)
+PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"   # collected by tools/pmc_traffic.py (separate rocprofv3 --pmc passes)
 T_TOK, T_IN, DH = 1500, 3000, 64
 
 
@@ -209,9 +209,83 @@ def dora_step(enc_name, per_gpu_batch, dev, world, steps=6, warmup=2):
                 times[k] += e[i].elapsed_time(e[i + 1]) / steps
             total += e[0].elapsed_time(e[4]) / steps
     assert torch.isfinite(loss).all()
+    import torch.distributed as tdist
     return {"ms": total, "split_ms": times, "per_gpu_batch": per_gpu_batch, "detectors": 2,
+            "allreduce": f"RCCL all_reduce(SUM) of ONE flat fp32 bucket, {(bucket.numel + 1) * 4 / 1e6:.1f} MB, world size {world}"
+                         if tdist.is_initialized() else "no process group: skipped",
             "trainable_params": int(bucket.numel), "adapter": f"DoRA r=8 alpha=32 on q,k,v ({len(targets)} modules on {enc_name})",
             "loss": float(loss.detach())}
+
+
+def config4_composed(dev, mel64, rank):
+    """BASELINE configs[3] end to end on one GPU: whisper-base + the 22-class head of Glitch_classification/src/model.py
+    behind BOTH front ends -- the log-mel extractor the reference's Glitch code calls (dataset.py:46) and the Q-transform
+    adapter BASELINE names (QTransformAdapter defaults, one detector, MLGWSC-1/train.py:78-154) -- strain in, argmax out."""
+    from gw_whisper_amd import ops, synth
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    from gw_whisper_amd.models import glitch_classifier
+    from gw_whisper_amd.qscan import QTransformAdapter
+    B = 64
+    enc = WhisperEncoder.from_numpy_state_dict(synth.named_encoder_state_dict("base", seed=0), WhisperConfig.named("base"),
+                                               precision="bf16")
+    model = glitch_classifier(enc, num_classes=22).to(dev).eval()
+    wave16k = torch.from_numpy(synth.strain_segments(B, seed=4000 + rank)).to(dev)
+    wave2k = torch.from_numpy(synth.strain_segments(B, seed=4100 + rank, n_samples=2048)).to(dev)[:, None, :]
+    adapter = QTransformAdapter.train_variant(n_detectors=1).to(dev).eval()
+    out = {}
+    with torch.no_grad():
+        ms_mel = time_kernel(lambda: model(ops.logmel(wave16k)).argmax(1), iters=5, warm=2)
+        ms_q = time_kernel(lambda: model(adapter(wave2k)[:, 0]).argmax(1), iters=5, warm=2)
+        labels = model(adapter(wave2k)[:, 0]).argmax(1)
+    assert labels.shape == (B,)
+    for k, ms in (("logmel_frontend", ms_mel), ("q_transform_frontend", ms_q)):
+        out[k] = {"batch": B, "ms_per_batch": ms, "segments_per_s_per_gpu": B / ms * 1e3}
+    out["workload"] = ("BASELINE configs[3]: strain -> front end -> whisper-base last token -> 22-class head -> argmax, "
+                       "B = 64, one GPU; Q front end = QTransformAdapter(128 x 128 Q-scan, CNN 32/64/128) -- parity unpinned "
+                       "(DESIGN.md section 2)")
+    return out
+
+
+def config5_composed(dev, rank, enc_names=("tiny", "small"), n_batches=4):
+    """BASELINE configs[4] on one GPU: the search loop of MLGWSC-1/inference.py:454-489 -- DeviceSegmentSlicer over a
+    seeded two-detector strain segment (0.1 s step), 256-window batches through QTransformAdapter(inference variant) ->
+    encoder -> MLP + Softmax head, threshold + clustering on the device -- windows/s per GPU and the projected wall time
+    of one month (2.59e7 windows) on 1 and 8 GPUs (replicas over batch-aligned window shards, no collective)."""
+    from gw_whisper_amd import inference as inf, synth
+    from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
+    from gw_whisper_amd.qscan import QTransformAdapter
+    n_win = 256 * n_batches
+    strain = synth.strain_segments(2, seed=5000 + rank, n_samples=2048 + (n_win - 1) * 204)
+    month = 30 * 86400 / 0.1
+    out = {}
+    for name in enc_names:
+        d = synth.ENCODER_SIZES[name][0]
+        enc = WhisperEncoder.from_numpy_state_dict(synth.named_encoder_state_dict(name, seed=0), WhisperConfig.named(name),
+                                                   precision="bf16")
+        model = inf.GWWhisperClassifier(enc, n_detectors=2, num_classes=2,
+                                        adapter=QTransformAdapter.inference_variant(n_detectors=2)).to(dev).eval()
+        sl = inf.DeviceSegmentSlicer(strain, start_time=0.0)
+        assert len(sl) == n_win
+
+        def run():
+            return inf.evaluate_slices(sl, model, trigger_threshold=0.2, batch_size=256, cluster_threshold=0.35)
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        trig, vals, clusters = run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        wps = n_win / dt
+        out[f"whisper_{name}"] = {"windows": n_win, "ms_per_256_window_batch": dt / n_batches * 1e3, "windows_per_s_per_gpu": wps,
+                                  "projected_month_hours_1gpu": month / wps / 3600, "projected_month_hours_8gpu": month / wps / 8 / 3600,
+                                  "triggers": len(trig), "clusters": int(len(clusters[0]))}
+        del model, enc, sl
+        torch.cuda.empty_cache()
+    out["workload"] = ("BASELINE configs[4]: sliding-window search, 2 detectors, QTransformAdapter(512 x 512 Q-scan, CNN 16/32/64) "
+                       "-> encoder -> head -> device threshold + clustering, whitening skipped (--white), host wall time incl. "
+                       "the two result copies per segment; reference hard-codes tiny (inference.py:408), BASELINE asks small: both; "
+                       "Q-scan parity unpinned (DESIGN.md section 2)")
+    return out
 
 
 def cpu_baseline(enc_name, budget_s=20.0):
@@ -272,10 +346,17 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    import torch.distributed as dist
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    elif not args.no_train and args.precision == "bf16":
+        # N = 1: a world-size-1 RCCL group, so that the DoRA step below goes through dist.init's path and
+        # FlatGradBucket.all_reduce_mean issues a real ncclAllReduce on the 6.1 MB (tiny) / 10.8 MB (small) bucket --
+        # `dora_step.split_ms.allreduce` is then a measured collective, not a skipped branch
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     from gw_whisper_amd import ops, synth
     from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder
@@ -312,8 +393,9 @@ def main():
     qs = QScan(duration=1.0, sample_rate=2048, spectrogram_shape=[128, 128], qrange=[4, 128])
     strain2k = torch.from_numpy(synth.strain_segments(2 * B, seed=2000 + rank, n_samples=2048)).to(dev)
     q_ms = time_kernel(lambda: qs(strain2k), iters=5, warm=1)
-    # the whole Q-transform adapter of BASELINE configs 4 / 5 (Q-scan -> small CNN (torch.nn) -> pool + affine + FiLM + stack
-    # as one HIP kernel), both variants of the reference, B two-detector windows; and that tail kernel alone
+    # the whole Q-transform adapter of BASELINE configs 4 / 5 (Q-scan -> the small CNN as three HIP launches, csrc/qadapter_cnn.hip
+    # -> pool + affine + FiLM + stack as one HIP kernel), both variants of the reference, B two-detector windows; and that
+    # tail kernel alone
     from gw_whisper_amd.qscan import QTransformAdapter, _AdapterTail
     adapter_ms = {}
     with torch.no_grad():
@@ -415,8 +497,8 @@ def main():
         tf_s = 64 * flops_per_segment(ds_, Ls_, Hs_, fs_)["total"] / (ms_s * 1e-3) / 1e12
         extra["whisper_small_forward"] = {"batch": 64, "ms_per_batch": ms_s, "segments_per_s_per_gpu": 64 / ms_s * 1e3,
                                           "achieved_tflops_per_gpu": tf_s, "frac_of_bf16_mfma_peak": tf_s / MFMA_BF16_PEAK_TFLOPS,
-                                          "workload": "BASELINE configs[2] / [4] encoder (generic per-op path: LayerNorm kernel + "
-                                                      "k_gemm_bf16_v3 + attention)"}
+                                          "workload": "BASELINE configs[2] / [4] encoder (per-op path: LayerNorm kernel + "
+                                                      "k_gemm_bf16_v4 + k_attention_w64_bf16)"}
         del enc_s
         torch.cuda.empty_cache()
         # the parity gate itself: GWW_PREC_F32 (exact fp32 MFMA, 1/16 of the bf16 rate) -- the mode whose logits match
@@ -434,6 +516,10 @@ def main():
         torch.cuda.empty_cache()
         extra["whisper_small_dora_step"] = dora_step("small", args.train_batch, dev, world, steps=4, warmup=2)
         extra["whisper_small_dora_step"]["workload"] = "BASELINE configs[2]: whisper-small + DoRA fine-tune, data-parallel"
+        torch.cuda.empty_cache()
+        extra["config4"] = config4_composed(dev, mel, rank)
+        torch.cuda.empty_cache()
+        extra["config5"] = config5_composed(dev, rank)
         torch.cuda.empty_cache()
 
     if rank == 0:
@@ -556,8 +642,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only (rank 0's host cores)
             line["cpu_baseline"] = cpu_baseline(args.encoder)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -94,6 +94,8 @@ SIGNATURES = {
                                 C.c_int, C.c_void_p]),
     "gww_gemm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                 C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gww_gemm_bf16_v4_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gww_gemm_astat_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gww_ln_fold_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int,
@@ -132,7 +134,7 @@ SIGNATURES = {
     "gww_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
 }
 
-ABI_VERSION = 104   # include/gww.h GWW_VERSION this binding was written against
+ABI_VERSION = 105   # include/gww.h GWW_VERSION this binding was written against
 
 _lib = None
 

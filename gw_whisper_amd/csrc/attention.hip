@@ -273,6 +273,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? GWW_ATT_MINBLK : 1) void k_atten
   ASTAMP_FLUSH
 }
 
+#ifdef GWW_LAB   // laboratory variant: compiled into libgww_lab.so only (make LAB=1)
 // ---------------------------------------------------------------------------------------------------------
 // The kernel the inference path launches (q in log2 units).  Same dataflow and occupancy as k_attention_bf16 above
 // (one tile = S, softmax, P V back to back; three waves per SIMD supply the overlap), with the instruction stream
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void k_attention_l2_bf16(
   }
 }
 
+#endif  // GWW_LAB
 // ---------------------------------------------------------------------------------------------------------
 // LDS-DMA form of k_attention_l2_bf16 (GWW_ATT_VAR = 4 / 5): K / V tiles go global -> LDS directly
 // (global_load_lds_dwordx4, the XOR swizzles applied on the per-lane SOURCE address, the LDS image stays lane-linear),
@@ -811,6 +813,7 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
 #endif
 }
 
+#ifdef GWW_LAB   // laboratory variant: compiled into libgww_lab.so only (make LAB=1)
 // ---------------------------------------------------------------------------------------------------------
 // Two-waves-per-SIMD "ping-pong" form (GWW_ATT_VAR = 8; correct -- every test_attention_log2q case runs it too -- but
 // MEASURED SLOWER than the three-waves-per-SIMD default: 1.10 - 1.21 ms against 0.98 - 1.03 per whisper-tiny layer at
@@ -1432,6 +1435,7 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : 512, 1) void k_attention_pp_bf16(
   }
 }
 
+#endif  // GWW_LAB
 // last_tile_only: compute only the query tile that holds token T - 1 (the other rows of ctx are left untouched) --
 // the pooled forward needs nothing else of the last layer's attention.
 // q_log2: q was projected with log2(e) / 8 instead of 1 / 8 (every bf16 q panel of the encoder is packed that way unless
@@ -1442,7 +1446,7 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : 512, 1) void k_attention_pp_bf16(
 //   k_attention_dma_bf16 VAR 4 / 5 / 6 / 7         1.00 - 1.06 / 1.08 / 1.07 - 1.12 / 1.02 - 1.04
 // (an earlier software-pipelined two-waves-per-SIMD kernel measured 1.20 ms and was removed.)
 bool attention_log2q_enabled() {
-  static const bool off = getenv("GWW_ATT_LOG2Q") && atoi(getenv("GWW_ATT_LOG2Q")) == 0;
+  static const bool off = lab_int("GWW_ATT_LOG2Q", 1) == 0;
   return !off;
 }
 
@@ -1452,16 +1456,25 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
   GWW_REQUIRE(B >= 0 && T > 0 && H > 0, "attention_bf16: bad shape B=%d T=%d H=%d", B, T, H);
   GWW_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)ctx) & 15) == 0, "attention_bf16: 16-byte alignment");
   if (B == 0) return GWW_OK;
-  const int nw_env = getenv("GWW_ATT_WAVES") ? atoi(getenv("GWW_ATT_WAVES")) : 0;   // tuning aid (natural-q kernel): 4 or 8
-  const int var_env = getenv("GWW_ATT_VAR") ? atoi(getenv("GWW_ATT_VAR")) : 7;     // read per call: in-process A/B
+  // the encoder's kernel: 64 query rows per wave, one wave per SIMD (attention_w64.hip); the pooled last layer's single
+  // query tile stays on the 128-row kernel below
+  if (q_log2 && !last_tile_only && lab_int("GWW_ATT_W64", 1) != 0) return launch_attention_w64_bf16(qkv, ctx, B, T, H, s, lse);
+  const unsigned short* in = (const unsigned short*)qkv;
+  unsigned short* out = (unsigned short*)ctx;
+#ifdef GWW_LAB
+  const int nw_env = (int)lab_int("GWW_ATT_WAVES", 0);   // tuning aid (natural-q kernel): 4 or 8
+  const int var_env = (int)lab_int("GWW_ATT_VAR", 7);    // read per call: in-process A/B
   const bool pp = q_log2 && var_env >= 8;   // the two-waves-per-SIMD ping-pong kernel: 256 query rows per workgroup
   const int nw = ((nw_env == 8 && !q_log2) || (pp && var_env == 8)) ? 8 : 4;
+#else
+  const int nw = 4;
+#endif
   const int all_tiles = (T + nw * 32 - 1) / (nw * 32);
   const int q_tiles = last_tile_only ? 1 : all_tiles, qt0 = last_tile_only ? all_tiles - 1 : 0;
   const long blocks = (long)q_tiles * B * H;
   GWW_REQUIRE(blocks < 2147483647L, "attention_bf16: grid too large");
-  const unsigned short* in = (const unsigned short*)qkv;
-  unsigned short* out = (unsigned short*)ctx;
+#define GWW_DMA(MW, MS, NM) hipLaunchKernelGGL((k_attention_dma_bf16<MW, MS, NM>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0)
+#ifdef GWW_LAB
   if (pp && var_env >= 9) {
     hipLaunchKernelGGL((k_attention_pp_bf16<1>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0);
   } else if (pp) {
@@ -1469,7 +1482,6 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
   } else if (q_log2) {
     const int var = var_env & 7;
 #define GWW_L2(VV) hipLaunchKernelGGL((k_attention_l2_bf16<4, VV>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0)
-#define GWW_DMA(MW, MS, NM) hipLaunchKernelGGL((k_attention_dma_bf16<MW, MS, NM>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0)
     switch (var) {
       case 0: GWW_L2(0); break;
       case 1: GWW_L2(1); break;
@@ -1481,12 +1493,18 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
       default: GWW_DMA(3, false, true); break;
     }
 #undef GWW_L2
-#undef GWW_DMA
   } else if (nw == 8) {
     hipLaunchKernelGGL(k_attention_bf16<8>, dim3((unsigned)blocks), dim3(512), 0, s, in, out, lse, T, H, q_tiles, qt0);
-  } else {
+  } else
+#else
+  if (q_log2) {   // log2-unit q, 128 query rows per workgroup: the pooled last layer's query tile
+    GWW_DMA(3, false, true);
+  } else
+#endif
+  {               // natural-unit q: the kernel-level entry point gww_attention_bf16
     hipLaunchKernelGGL(k_attention_bf16<4>, dim3((unsigned)blocks), dim3(256), 0, s, in, out, lse, T, H, q_tiles, qt0);
   }
+#undef GWW_DMA
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }

@@ -112,6 +112,15 @@ __device__ __forceinline__ float dgelu_fast(float z) {
 
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
+// Laboratory switches (kernel variants kept for A/B measurements, tuning aids): read from the environment ONLY in the
+// -DGWW_LAB build that tools/ use (make LAB=1 -> libgww_lab.so).  In the product library they are compile-time constants:
+// no environment variable changes what libgww.so computes or launches (no global mutable state).
+#ifdef GWW_LAB
+long lab_int(const char* name, long dflt);   // encoder.hip
+#else
+constexpr long lab_int(const char*, long dflt) { return dflt; }
+#endif
+
 // ---- kernels launched from more than one translation unit ------------------
 // (definitions in the .hip files; every launcher returns a gww status code)
 int launch_layernorm(const float* x, const float* w, const float* b, void* y, int out_bf16,
@@ -131,7 +140,7 @@ int launch_gemm_bf16(const void* A, long lda, const void* W, const float* bias, 
                      const float* pos, void* C, long M, int N, int K, int epi, int rows_per_batch,
                      hipStream_t s, int rows_padded_256 = 0);
 int launch_gemm_bf16_v4(const void* A, long lda, const void* W, const float* bias, const float* resid, void* C, long M,
-                        int N, int K, int epi, hipStream_t s);
+                        int N, int K, int epi, hipStream_t s, int force_split = 0);
 int launch_gemm_fulln(const void* A, long lda, const void* W, const float* bias, const float* pos, void* C,
                       long M, int N, int K, int epi, int rows_per_batch, hipStream_t s);
 int launch_gemm_f32(const float* A, long lda, const float* W, const float* bias, const float* resid,
@@ -139,6 +148,7 @@ int launch_gemm_f32(const float* A, long lda, const float* W, const float* bias,
                     hipStream_t s);
 int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipStream_t s, float* lse = nullptr,
                           bool last_tile_only = false, bool q_log2 = false);
+int launch_attention_w64_bf16(const void* qkv, void* ctx, int B, int T, int H, hipStream_t s, float* lse);
 bool attention_log2q_enabled();   // the inference path packs q in log2 units (attention.hip)
 int launch_attention_f32(const float* qkv, float* ctx, int B, int T, int H, hipStream_t s);
 int launch_conv1_bf16(const float* mel, const void* w_packed, const float* bias, void* out,

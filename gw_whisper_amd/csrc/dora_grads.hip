@@ -345,7 +345,7 @@ int launch_dora_grads_multi(const void* X, long ldx, const void* dY, const void*
                 "dora_grads_multi: bad projection %d", p);
     pr.p[p] = DoraProj{A[p], Bm[p], mag[p], nrm[p], bias_st[p], dA[p], dB[p], dm[p], yscale[p], scaling[p], col_off[p]};
   }
-  static const long nb_env = getenv("GWW_DORA_BLOCKS") ? atol(getenv("GWW_DORA_BLOCKS")) : 0;   // tuning aid
+  static const long nb_env = lab_int("GWW_DORA_BLOCKS", 0);   // tuning aid (lab build)
   long nb = cdiv(M, 32);
   const long nb_max = nb_env > 0 && nb_env < 256 ? nb_env : 256;   // one workgroup per CU (LDS); one slab each
   if (nb > nb_max) nb = nb_max;

@@ -21,6 +21,13 @@
 #include <vector>
 
 namespace gww {
+#ifdef GWW_LAB
+long lab_int(const char* name, long dflt) {   // the laboratory build's only environment reader (common.h)
+  const char* e = getenv(name);
+  return e ? atol(e) : dflt;
+}
+#endif
+
 int launch_transpose_bf16(const void* in, void* out, int R, int Cn, hipStream_t s);
 int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int dy_f32, float* dx, int accumulate,
                   void* dx_bf16, long M, int d, hipStream_t s);
@@ -357,7 +364,7 @@ static int pack_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_
       // Only the stream the active path consumes is packed: the inference and the training forward both run the block with
       // out_proj in front (wmlp_op); the stream without it serves the debug paths GWW_GENERIC_PATH bits 4 / 7 alone (a
       // DoRA step used to pay two full fc1 + fc2 + q/k/v stream packs per layer, 2 x 3.2 MB of writes, for one consumer).
-      static const bool plain_stream = getenv("GWW_GENERIC_PATH") && (atoi(getenv("GWW_GENERIC_PATH")) & (16 | 128));
+      static const bool plain_stream = (lab_int("GWW_GENERIC_PATH", 0) & (16 | 128)) != 0;
       if (plain_stream && ((m & 12u) || (mn & 1u))) GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, wq_next, w.wmlp, d, F, 3 * d, s));
       GWW_TRY(launch_mlp_pack(w.w1_ln, w.w2, wq_next, w.wmlp_op, d, F, 3 * d, s, w.wo));
     }
@@ -514,7 +521,7 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   // A-stationary kernels (A panel in registers, fused residual-add + LayerNorm prologue) for K = d <= 512
   // GWW_GENERIC_PATH (debug aid): bit 0 = generic layer GEMMs, bit 1 = generic conv1, bit 2 = generic conv2, bit 3 = unfused MLP,
   // bit 4 = stand-alone QKV, bit 5 = no pooled last layer, bit 6 = layer 0's LN1 + QKV by the LN-fused A-stationary GEMM, bit 7 = stand-alone out_proj, bit 8 = stand-alone final LayerNorm, bit 9 = A-stationary layer GEMMs at d = 512
-  static const int generic_mask = getenv("GWW_GENERIC_PATH") ? atoi(getenv("GWW_GENERIC_PATH")) : 0;
+  static const int generic_mask = (int)lab_int("GWW_GENERIC_PATH", 0);   // (0 in the product build)
   // d = 512 (whisper-base): since round 3 the LayerNorm kernel + the 256 x 256 GEMM (k_gemm_bf16_v3) beat the LN-fused
   // A-stationary layer GEMMs there (8.78 against 9.33 ms per 64 segments; bit 9 of the mask brings them back)
   const bool astat = bf && (d == 384 || (d == 512 && (generic_mask & 512))) && F % 128 == 0 && !(generic_mask & 1);
@@ -592,7 +599,7 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
         qkv_done = true;
         continue;
       }
-      static const bool fuse_final = !(getenv("GWW_GENERIC_PATH") && (atoi(getenv("GWW_GENERIC_PATH")) & 256));   // bit 8: stand-alone final LayerNorm
+      static const bool fuse_final = !(lab_int("GWW_GENERIC_PATH", 0) & 256);   // bit 8: stand-alone final LayerNorm
       if (mlp_fused && op && fuse_final && i == e->cfg.n_layers - 1 && last_hidden) {
         // the LAST block with the encoder's final LayerNorm as its epilogue: last_hidden_state comes straight out of the
         // kernel (no bf16 delta, no second read of the residual stream, no LayerNorm launch); the pooled token is row
@@ -673,7 +680,7 @@ extern "C" int gww_encoder_forward(gww_encoder* e, const float* mel, int batch, 
     return fail(GWW_ERR_WORKSPACE, "gww_encoder_forward: workspace %zu bytes < required %zu", workspace_bytes, w0 + w1);
   GWW_HIP(hipEventRecord(e->ev_fork, s));
   int off = 0;
-  static const int skew = getenv("GWW_SPLIT_SKEW") ? atoi(getenv("GWW_SPLIT_SKEW")) : 0;   // tuning aid
+  static const int skew = (int)lab_int("GWW_SPLIT_SKEW", 0);   // tuning aid (lab build)
   for (int i = 0; i < 2; ++i) {
     GWW_HIP(hipStreamWaitEvent(e->s2[i], e->ev_fork, 0));
     if (i == 1 && skew) GWW_HIP(hipStreamWaitEvent(e->s2[1], e->ev_skew, 0));
@@ -755,7 +762,7 @@ TrainWs train_ws(const gww_enc_cfg& c, int B) {
 
 // d = 384: the training forward runs on the fused inference kernels (GWW_TRAIN_FUSED=0: the per-op forward of round 1)
 static bool train_fused(const gww_enc_cfg& c) {
-  static const bool off = getenv("GWW_TRAIN_FUSED") && atoi(getenv("GWW_TRAIN_FUSED")) == 0;
+  static const bool off = lab_int("GWW_TRAIN_FUSED", 1) == 0;
   return !off && c.d_model == 384 && c.ffn % 128 == 0 && c.ffn <= 1536;
 }
 
@@ -847,7 +854,7 @@ extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int b
       GWW_TRY(launch_attention_bf16(qkv, ctx, B, T, H, s, lse, false, q_log2));
       // out_proj fused in front of the block as on the inference path: x_mid = x_in + bf16(ctx W_o^T + bo) comes out of
       // the kernel's seam (the backward needs ctx and x_mid, never the delta)
-      static const bool op = !(getenv("GWW_GENERIC_PATH") && (atoi(getenv("GWW_GENERIC_PATH")) & 128));
+      static const bool op = !(lab_int("GWW_GENERIC_PATH", 0) & 128);
       if (!op)
         GWW_TRY(launch_gemm_astat(ctx, d, nullptr, nullptr, nullptr, nullptr, W.wo, W.bo, d1, M, d, d, EPI_BIAS, 0, s));
       const void* a2 = op ? (const void*)ctx : (const void*)d1;
@@ -954,7 +961,7 @@ extern "C" int gww_encoder_train_backward(gww_encoder* e, int batch, void* works
   };
   // the stored q is  q_ysc * (W' x + b): 1 / 8 (head_dim^-0.5), times log2(e) when the bf16 panels carry log2 units
   const float q_ysc = attention_log2q_enabled() ? 0.125f * 1.44269504088896340736f : 0.125f;
-  bool multi_ok = (d == 384 || d == 512) && !getenv("GWW_DORA_OLD");
+  bool multi_ok = (d == 384 || d == 512) && lab_int("GWW_DORA_OLD", 0) == 0;
   for (int i = 0; i < n_targets; ++i) multi_ok = multi_ok && targets[i].r == 8;
   // final LayerNorm backward -> dx (grad w.r.t. x_in[L]); pooled: on the B last-token rows only
   GWW_TRY(launch_ln_bwd(x_in(L), e->lnw, d_last_hidden, 1, dx, 0, dxb, pooled ? B : M, d, s));

@@ -443,7 +443,7 @@ extern "C" int gww_gemm_astat_bf16(const void* A, const void* delta, float* x_ou
                                    int K, int epilogue, void* stream) {
   GWW_REQUIRE(epilogue == 0 || epilogue == 1, "gww_gemm_astat_bf16: epilogue must be 0 (bias) or 1 (GELU)");
   GWW_REQUIRE((ln_u == nullptr) == (ln_cb == nullptr), "gww_gemm_astat_bf16: ln_u and ln_cb go together");
-  static const long dbg_panel = getenv("GWW_ASTAT_PANEL") ? atol(getenv("GWW_ASTAT_PANEL")) : 0;   // tuning aid
+  static const long dbg_panel = lab_int("GWW_ASTAT_PANEL", 0);   // tuning aid (lab build)
   return launch_gemm_astat(A, K, delta, x_out, ln_u, ln_cb, W, bias, C, M, N, K, epilogue, 0, (hipStream_t)stream,
                            dbg_panel ? (M + 255) / 256 * 256 : 0);
 }

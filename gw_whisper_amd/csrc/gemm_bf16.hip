@@ -512,12 +512,12 @@ int launch_gemm_bf16(const void* A, long lda, const void* W, const float* bias, 
   } else if (epi == EPI_RESID) {
     GWW_REQUIRE(resid != nullptr, "gemm_bf16: residual epilogue needs resid");
   }
-  static const bool use_v4 = !(getenv("GWW_GEMM_V4") && atoi(getenv("GWW_GEMM_V4")) == 0);
+  static const bool use_v4 = lab_int("GWW_GEMM_V4", 1) != 0;
   if (use_v4 && rows_padded_256) {   // 256 x 256 x 64 eight-phase form (gemm_v4.hip); -1: not its shape
     const int rc = launch_gemm_bf16_v4(A, lda, W, bias, resid, C, M, N, K, epi, s);
     if (rc != -1) return rc;
   }
-  static const bool use_v3 = !(getenv("GWW_GEMM_V3") && atoi(getenv("GWW_GEMM_V3")) == 0);
+  static const bool use_v3 = lab_int("GWW_GEMM_V3", 1) != 0;
   if (use_v3 && rows_padded_256 && N % BN3 == 0 && N <= 12288 && M >= 4096 &&
       (epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID)) {
     // wide panels (whisper-base / -small): 256 x 256 tiles.  A block's bias slice lives in 1536 floats of LDS: at most

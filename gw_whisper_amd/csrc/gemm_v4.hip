@@ -120,6 +120,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
     first_item = c0 + bi;
     n_my = (clen - bi + item_stride - 1) / item_stride;
   }
+  if (n_my <= 0) return;   // (block-uniform, in front of every barrier: a CU count that is no multiple of 8 leaves such blocks)
   const int n_tiles = n_my * tpi;
   const int total = n_tiles * nk;
   // tile i of this block -> first row and column tile
@@ -485,8 +486,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
 }
 
 // returns GWW_OK after a launch, -1 when the shape is not this kernel's (the caller falls back to v3 / v2)
+// force_split > 0 (the kernel-level entry point gww_gemm_bf16_v4_split): that column split (a divisor of N / 256)
+// instead of the automatic choice -- an output element's accumulation order does not depend on it, which is what the
+// split-invariance test checks bit for bit
 int launch_gemm_bf16_v4(const void* A, long lda, const void* W, const float* bias, const float* resid, void* C, long M,
-                        int N, int K, int epi, hipStream_t s) {
+                        int N, int K, int epi, hipStream_t s, int force_split) {
   // (no lower bound on M: a segment's rows must not depend on how many segments share the launch -- the batch-independence
   // property the tests check bit for bit -- so the kernel choice may depend on N and K only)
   if (N % 256 != 0 || K % 128 != 0 || N > BIAS4 || M < 1) return -1;
@@ -519,9 +523,10 @@ int launch_gemm_bf16_v4(const void* A, long lda, const void* W, const float* bia
       if (eff > best + 0.01) { best = eff; n_split = s2; }   // ties: the fewer, longer items
     }
   }
-  if (const char* e = getenv("GWW_G4_NSPLIT")) {   // tuning aid: force the column split (a divisor of N / 256)
-    const int f = atoi(e);
-    if (f >= 1 && f <= tn && tn % f == 0) n_split = f;
+  if (force_split > 0) {
+    GWW_REQUIRE(force_split <= tn && tn % force_split == 0, "gemm_bf16_v4: column split %d does not divide %d column tiles",
+                force_split, tn);
+    n_split = force_split;
   }
   const long n_items = panels * n_split;
   GWW_REQUIRE(n_items < 2147483647L, "gemm_bf16: grid too large");
@@ -544,6 +549,16 @@ int launch_gemm_bf16_v4(const void* A, long lda, const void* W, const float* bia
 }
 
 }  // namespace gww
+
+extern "C" int gww_gemm_bf16_v4_split(const void* A, const void* W, const float* bias, const float* resid, void* C, long M,
+                                      int N, int K, int epilogue, int n_split, void* stream) {
+  GWW_REQUIRE(epilogue >= 0 && epilogue <= 2, "gww_gemm_bf16_v4_split: epilogue must be 0, 1 or 2");
+  GWW_REQUIRE(M % 256 == 0, "gww_gemm_bf16_v4_split: M must be a multiple of 256 (got %ld)", M);
+  GWW_REQUIRE(epilogue != 2 || resid != nullptr, "gww_gemm_bf16_v4_split: residual epilogue needs resid");
+  const int rc = gww::launch_gemm_bf16_v4(A, K, W, bias, resid, C, M, N, K, epilogue, (hipStream_t)stream, n_split);
+  if (rc == -1) return gww::fail(GWW_ERR_ARG, "gww_gemm_bf16_v4_split: not a shape of the 256 x 256 x 64 kernel (N=%d K=%d)", N, K);
+  return rc;
+}
 
 #ifdef GWW_G4_STAMP
 extern "C" int gww_debug_stamps_v4(unsigned long long* out32, int reset) {

@@ -432,7 +432,7 @@ extern "C" int gww_logmel_f32(gww_frontend* fe, const float* wave, int n_seg, in
     if (live < 1) live = 1;
   }
   GWW_HIP(hipMemsetAsync(seg_max, 0, sizeof(float) * (size_t)n_seg, s));
-  static const bool valu_kernel = getenv("GWW_LOGMEL_VALU") != nullptr;   // comparison aid
+  static const bool valu_kernel = lab_int("GWW_LOGMEL_VALU", 0) != 0;   // comparison aid (lab build)
   if (valu_kernel) {
     dim3 g1((unsigned)cdiv(live, kFT), (unsigned)n_seg);
     hipLaunchKernelGGL(k_logmel_frames, g1, dim3(256), 0, s, wave, wave_stride, n_eff, live, fe->tb, out,

@@ -250,8 +250,11 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   MSTAMP_DECL
   for (int i = tid; i < F; i += MF_THREADS) {
     lds_cb[i] = GWW_MF_SCHED ? ln_cb[i] * 0.125f : ln_cb[i];   // SCHED: the fc1 accumulators hold S / 8 (gelu_slice)
-    lds_u[i] = ln_u[i];
+    // (u is only read by round 1's per-value LayerNorm algebra; with NORM the table stays unwritten here, so the final-LN
+    // staging below -- MODE 3 keeps its gain / bias in the same place -- has no second writer in another wave)
+    if (!GWW_MF_NORM) lds_u[i] = ln_u[i];
   }
+  if (!GWW_MF_NORM && FIN) __syncthreads();
   if (!LNQ)
     for (int i = tid; i < MF_D; i += MF_THREADS) lds_b2[i] = b2[i];
   if (OP)
@@ -1355,7 +1358,7 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
   if (M == 0) return GWW_OK;
   const long panels = cdiv(M, MF_BM);
   // stagger only when there is more than one round of workgroups to keep de-phased; 100 MHz ticks
-  static const int stagger_env = getenv("GWW_MLP_STAGGER") ? atoi(getenv("GWW_MLP_STAGGER")) : 0;
+  static const int stagger_env = (int)lab_int("GWW_MLP_STAGGER", 0);   // (lab build; measured: no effect)
   const int stagger = panels >= 512 ? stagger_env : 0;
 #define GWW_MF_LAUNCH(QQ, OO, ...)                                                                                        \
   hipLaunchKernelGGL((k_mlp_fused<QQ, OO>), dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta, \

@@ -608,7 +608,7 @@ int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, lo
   GWW_REQUIRE(r == 8 && (d == 128 || d == 384 || d == 512 || d == 768 || d == 1024 || d == 1280),
               "dora_grads: only r = 8 and d in {128, 384, 512, 768, 1024, 1280} (got d=%d r=%d)", d, r);
   if (M == 0) return GWW_OK;
-  static const int old_kernel = getenv("GWW_DORA_OLD") ? atoi(getenv("GWW_DORA_OLD")) : 0;   // comparison aid: 1 = VALU
+  static const int old_kernel = (int)lab_int("GWW_DORA_OLD", 0);   // comparison aid: 1 = VALU
   // kernels only, 2 = register-blocked VALU kernel instead of the MFMA kernel
   if ((d == 384 || d == 512 || d == 768) && !old_kernel) {   // matrix-core kernel (dora_grads.hip)
     const long off = 0;
@@ -616,7 +616,7 @@ int launch_dora_grads(const void* X, long ldx, const void* dY, const void* Y, lo
                                    &dm, M, d, s, scratch, scratch_bytes);
   }
   if (d <= 768 && d != 128 && old_kernel != 1) {
-    static const long nb_env = getenv("GWW_DORA_BLOCKS") ? atol(getenv("GWW_DORA_BLOCKS")) : 0;   // tuning aid
+    static const long nb_env = lab_int("GWW_DORA_BLOCKS", 0);   // tuning aid (lab build)
     const int rt = d <= 512 ? 16 : 8;
     long nb = cdiv(M, rt);
     const long nb_max = nb_env > 0 ? nb_env : 256;     // one workgroup per CU: fewer contended atomics at the end

@@ -130,11 +130,15 @@ class FlatGradBucket:
         collective.  Without it: the plain mean over ``active`` (default ``world``) ranks.
         """
         grouped = _group_up()
+        if world > 1 and not grouped:
+            raise RuntimeError("FlatGradBucket.all_reduce_mean: world > 1 but no process group is initialised "
+                               "(call gw_whisper_amd.dist.init first): the gradients would be divided without being summed")
         if n_local is not None:
+            if not grouped:   # a single process: n g / n is g -- leave the gradient bit for bit as the backward wrote it
+                return
             self.flat.mul_(float(n_local))
             self._buf[self.numel] = float(n_local)
-            if grouped:
-                dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)
             self.flat.div_(self._buf[self.numel].clamp_min(1.0))
             return
         if grouped:

@@ -121,6 +121,25 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, epi
     return c
 
 
+def gemm_v4_split(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, epilogue: int = 0,
+                  resid: torch.Tensor | None = None, n_split: int = 0) -> torch.Tensor:
+    """``gemm`` on the 256 x 256 x 64 kernel of the wide encoders with an explicit column split of its work items
+    (``gww_gemm_bf16_v4_split``; 0 = the automatic choice).  bf16 A [M % 256 == 0, K] / W [N, K]."""
+    a = _dev(a, torch.bfloat16, "A")
+    w = _dev(w, torch.bfloat16, "W")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise _lib.GwwError(f"gemm_v4_split: A is [{M},{K}] but W is {tuple(w.shape)}")
+    c = torch.empty((M, N), dtype=torch.float32 if epilogue == _lib.EPI_RESID else torch.bfloat16, device=a.device)
+    bptr = _dev(bias, torch.float32, "bias").data_ptr() if bias is not None else None
+    rptr = _dev(resid, torch.float32, "resid").data_ptr() if resid is not None else None
+    with torch.cuda.device(a.device):
+        check(lib().gww_gemm_bf16_v4_split(a.data_ptr(), w.data_ptr(), bptr, rptr, c.data_ptr(), M, N, K, epilogue,
+                                           int(n_split), _stream()), "gww_gemm_bf16_v4_split")
+    return c
+
+
 def ln_fold_weights(w: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, bias=None, scale: float = 1.0):
     """Fold LayerNorm(gain ln_w, shift ln_b) into the Linear (w fp32 [N,K], bias) that follows it.
     Returns (w_folded bf16 [N,K], u fp32 [N], cb fp32 [N]) for ``gemm_astat(..., ln=(u, cb))``."""

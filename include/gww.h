@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GWW_VERSION 104  /* 0.1.4: gww_mlp_fused_bf16 / gww_attn_out_mlp_fused_bf16 with the q / k / v tail return x_next over x (x_out keeps x_new); 0.1.3: + gww_logmel_host_f32 (fork-safe CPU twin of the front end); 0.1.2: + whitening kernels, gww_qadapter_tail_f32, gww_attention_bwd_log2q_bf16, gww_lnqkv_fused_bf16, gww_attn_out_mlp_fused_bf16, gww_mlp_pack_op_bf16; the gww_mlp_pack_bf16 stream carries W1 / 8 and 8 W2 */
+#define GWW_VERSION 105  /* 0.1.5: + gww_gemm_bf16_v4_split (explicit column split; no environment switch is read by the library any more); 0.1.4: gww_mlp_fused_bf16 / gww_attn_out_mlp_fused_bf16 with the q / k / v tail return x_next over x (x_out keeps x_new); 0.1.3: + gww_logmel_host_f32 (fork-safe CPU twin of the front end); 0.1.2: + whitening kernels, gww_qadapter_tail_f32, gww_attention_bwd_log2q_bf16, gww_lnqkv_fused_bf16, gww_attn_out_mlp_fused_bf16, gww_mlp_pack_op_bf16; the gww_mlp_pack_bf16 stream carries W1 / 8 and 8 W2 */
 
 #define GWW_OK 0
 #define GWW_ERR_ARG (-1)      /* bad argument (shape, null pointer, unsupported size) */
@@ -206,6 +206,11 @@ int gww_layernorm(const float* x, const float* w, const float* b, void* y, int o
  * f32 variant : everything fp32. */
 int gww_gemm_bf16(const void* A, const void* W, const float* bias, const float* resid, void* C,
                   long M, int N, int K, int epilogue, void* stream);
+/* The 256 x 256 x 64 kernel of the wide encoders (csrc/gemm_v4.hip; what gww_gemm_bf16 picks for N % 256 == 0,
+ * N <= 3072, K % 128 == 0, M % 256 == 0) with the column split of its work items given explicitly: n_split = 0 is the
+ * automatic choice, n_split > 0 must divide N / 256.  Results do not depend on n_split bit for bit (tests). */
+int gww_gemm_bf16_v4_split(const void* A, const void* W, const float* bias, const float* resid, void* C,
+                           long M, int N, int K, int epilogue, int n_split, void* stream);
 /* A-stationary bf16 GEMM for K in {256, 384, 512}, N % 128 == 0 (QKV / fc1 / out_proj at
  * whisper-tiny/base): C = epi(f(A) @ W^T + bias), C bf16, epilogue 0 (bias) or 1 (GELU).
  *   ln_u == NULL : A is bf16 [M,K], W the plain bf16 [N,K] panel.

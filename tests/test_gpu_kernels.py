@@ -143,10 +143,11 @@ def test_gemm_bf16(T, gww, M, N, K, epi):
 
 @pytest.mark.parametrize("M,N,K", [(4096, 1536, 384), (66560, 1536, 256), (2560, 3072, 128)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-def test_gemm_v4_result_does_not_depend_on_the_column_split(T, gww, monkeypatch, M, N, K, epi):
+def test_gemm_v4_result_does_not_depend_on_the_column_split(T, gww, M, N, K, epi):
     """k_gemm_bf16_v4: an output element's accumulation order does not depend on how the column tiles are dealt to work
-    items, so every column split (GWW_G4_NSPLIT: 1 .. N / 256 tiles per item, i.e. one to many tiles per item, items per
-    block and residual preloads across tile AND item boundaries) must give bit-identical results -- and the fp64 product."""
+    items, so every column split (gww_gemm_bf16_v4_split: 1 .. N / 256 tiles per item, i.e. one to many tiles per item,
+    items per block and residual preloads across tile AND item boundaries) must give bit-identical results -- and the fp64
+    product."""
     from gw_whisper_amd import ops
     rng = np.random.default_rng(M + N + K + epi)
     a = T.from_numpy(_bf(rng.standard_normal((M, K)))).cuda().bfloat16()
@@ -156,10 +157,9 @@ def test_gemm_v4_result_does_not_depend_on_the_column_split(T, gww, monkeypatch,
     tn = N // 256
     outs = {}
     for split in [s for s in range(1, tn + 1) if tn % s == 0]:
-        monkeypatch.setenv("GWW_G4_NSPLIT", str(split))
-        outs[split] = ops.gemm(a, w, bias, epilogue=epi, resid=resid)
-    monkeypatch.delenv("GWW_G4_NSPLIT")
+        outs[split] = ops.gemm_v4_split(a, w, bias, epilogue=epi, resid=resid, n_split=split)
     auto = ops.gemm(a, w, bias, epilogue=epi, resid=resid)
+    assert T.equal(auto, ops.gemm_v4_split(a, w, bias, epilogue=epi, resid=resid, n_split=0))   # gww_gemm_bf16 took this kernel
     for split, o in outs.items():
         assert T.equal(o, auto), f"split {split} differs from the automatic split"
     if M <= 4096:
@@ -320,19 +320,19 @@ def _attn_ref_log2q(qkv_l2, H):
     return o.transpose(0, 2, 1, 3).reshape(B, Tn, d)
 
 
-@pytest.fixture(params=["default", "var0", "var1", "var2", "var3", "var4", "var5", "var6", "var8", "var9"])
-def att_variant(request, monkeypatch):
-    """The log2-unit-q kernels: k_attention_dma_bf16 (default = GWW_ATT_VAR 7; 4 .. 6 its variants), the
-    register-staged k_attention_l2_bf16 (0 .. 3), the two-waves-per-SIMD k_attention_pp_bf16 (8) and its interleaved
-    one-wave-per-SIMD form (9); the launcher reads GWW_ATT_VAR per call."""
-    v = request.param
-    if v.startswith("var"):
-        monkeypatch.setenv("GWW_ATT_VAR", v[-1])
-    return v
+@pytest.fixture(params=["default"])
+def att_variant(request):
+    """The log2-unit-q kernel of the product library: k_attention_w64_bf16 (64 query rows per wave, one wave per SIMD).
+    The kept-off variants (k_attention_l2_bf16, k_attention_pp_bf16, the other k_attention_dma_bf16 instantiations) are
+    compiled into the laboratory build only (make LAB=1 -> libgww_lab.so, where GWW_ATT_VAR / GWW_ATT_W64 select them);
+    k_attention_dma_bf16<3, false, true> stays in the product for the pooled last layer's single query tile and is
+    covered by the encoder goldens (tests/test_gpu_encoder.py, last_token)."""
+    return request.param
 
 
 @pytest.mark.parametrize("B,Tn,H", [(1, 64, 1), (1, 37, 1), (2, 200, 2), (1, 128, 1), (1, 192, 2), (1, 1500, 2),
-                                    (3, 129, 6), (2, 257, 1), (1, 1, 1), (2, 65, 2)])
+                                    (3, 129, 6), (2, 257, 1), (1, 1, 1), (2, 65, 2), (1, 256, 1), (2, 300, 3), (1, 513, 2),
+                                    (1, 31, 2), (1, 33, 1), (2, 96, 1), (1, 1472, 1)])
 def test_attention_log2q(T, gww, att_variant, B, Tn, H):
     """The log2-unit-q kernel (reference through the matrix pipe, first tile re-based, deferred re-basing later):
     one, two, three ... tiles, ragged and full last tiles, a single key, and the log-sum-exp it hands to

@@ -5,6 +5,11 @@ asynchronously).  Check in the ISA that, after every such load, the first instru
 destination registers is a v_mfma that reads them as its C operand, that at least one s_waitcnt
 vmcnt lies in between, and that no scratch (spill) access exists in the kernel -- a copy, an early read or a spill would
 use the registers before the data has landed / would sit uncounted in the hand-counted vmcnt queue.
+Scope: the walk follows the LAYOUT path (fall-through and unconditional branches) to the first instruction that names a
+destination register.  Taken conditional branches are not explored: a worklist over both successors (tried in round 4)
+reports only infeasible paths here -- the kernel's conditions (first / last / has_next) are correlated across blocks, and
+the registers are legitimately reused behind the loop -- so a copy on a taken-branch path would go unseen; the scratch
+check and the kernel's fp64 / split-invariance tests are the backstop for that case.
 usage: audit_asm_preload.py file.s kernel-name-substring"""
 import re, sys
 
@@ -40,7 +45,6 @@ def audit(lines):
             used = set()
             for t in toks: used |= regs(t)
             if not (used & dst): continue
-            if l2.startswith("global_load_dwordx4") and regs(l2.split()[1].rstrip(",")) == dst and False: break
             ops = [t.strip() for t in l2.split(None, 1)[1].split(",")]
             if l2.startswith("v_mfma") and regs(ops[3].split()[0]) == dst and waited: break   # (hipcc may rotate the destination)
             bad.append(f"line {ln}: {l}  -> first use line {ln2}: {l2} (waited={waited})")
@@ -51,7 +55,9 @@ if __name__ == "__main__":
     text = open(sys.argv[1]).read().split("\n")
     name = sys.argv[2]
     start = next(i for i, l in enumerate(text) if name in l and re.match(r"^[A-Za-z_][\w$.]*:", l))
-    end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
+    # the kernel's body ends at its .Lfunc_end marker (an s_endpgm may sit in the middle, behind an early-exit branch)
+    end = next((i for i in range(start, len(text)) if text[i].startswith(".Lfunc_end")),
+               max(i for i in range(start, len(text)) if "s_endpgm" in text[i]) + 1)
     n, bad = audit(text[start:end])
     for b in bad: print("AUDIT FAIL:", b)
     print(f"audit_asm_preload: {n} asm loads checked, {len(bad)} problems")
