@@ -1456,9 +1456,14 @@ int launch_attention_bf16(const void* qkv, void* ctx, int B, int T, int H, hipSt
   GWW_REQUIRE(B >= 0 && T > 0 && H > 0, "attention_bf16: bad shape B=%d T=%d H=%d", B, T, H);
   GWW_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)ctx) & 15) == 0, "attention_bf16: 16-byte alignment");
   if (B == 0) return GWW_OK;
-  // the encoder's kernel: 64 query rows per wave, one wave per SIMD (attention_w64.hip); the pooled last layer's single
-  // query tile stays on the 128-row kernel below
-  if (q_log2 && !last_tile_only && lab_int("GWW_ATT_W64", 1) != 0) return launch_attention_w64_bf16(qkv, ctx, B, T, H, s, lse);
+  // k_attention_w64_bf16 (attention_w64.hip: 64 query rows per wave, one wave per SIMD, the softmax hand-placed into the
+  // MFMA gaps) is correct -- every test_attention_log2q case passes on it -- and MEASURED SLOWER than the kernel below:
+  // 1.15 - 1.16 ms against 0.98 - 0.99 per whisper-tiny layer at B = 256 (profiles/r04_attention_w64.md: 56 % matrix-pipe
+  // busy inside a workgroup's life, but a fifth of that life is the prologue / epilogue no second workgroup covers at one
+  // wave per SIMD).  It is compiled into the laboratory build only (make LAB=1, GWW_ATT_W64=1).
+#ifdef GWW_LAB
+  if (q_log2 && !last_tile_only && lab_int("GWW_ATT_W64", 0) != 0) return launch_attention_w64_bf16(qkv, ctx, B, T, H, s, lse);
+#endif
   const unsigned short* in = (const unsigned short*)qkv;
   unsigned short* out = (unsigned short*)ctx;
 #ifdef GWW_LAB

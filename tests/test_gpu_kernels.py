@@ -322,11 +322,10 @@ def _attn_ref_log2q(qkv_l2, H):
 
 @pytest.fixture(params=["default"])
 def att_variant(request):
-    """The log2-unit-q kernel of the product library: k_attention_w64_bf16 (64 query rows per wave, one wave per SIMD).
-    The kept-off variants (k_attention_l2_bf16, k_attention_pp_bf16, the other k_attention_dma_bf16 instantiations) are
-    compiled into the laboratory build only (make LAB=1 -> libgww_lab.so, where GWW_ATT_VAR / GWW_ATT_W64 select them);
-    k_attention_dma_bf16<3, false, true> stays in the product for the pooled last layer's single query tile and is
-    covered by the encoder goldens (tests/test_gpu_encoder.py, last_token)."""
+    """The log2-unit-q kernel of the product library: k_attention_dma_bf16<3, false, true>.  The kept-off variants
+    (k_attention_l2_bf16, k_attention_pp_bf16, the other k_attention_dma_bf16 instantiations and round 4's one-wave-per-SIMD
+    k_attention_w64_bf16) are compiled into the laboratory build only (make LAB=1 -> libgww_lab.so, where GWW_ATT_VAR /
+    GWW_ATT_W64 select them; tools/run/att_w64_ab.py runs these same cases' shapes on both)."""
     return request.param
 
 
