@@ -347,16 +347,35 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
+
+    class _stdout_to_stderr:
+        """RCCL prints its version banner on the process's stdout (fd 1) when a communicator comes up; the driver parses
+        stdout as ONE JSON line, so fd 1 points at stderr while the group is created."""
+        def __enter__(self):
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+        def __exit__(self, *exc):
+            sys.stdout.flush()
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+
+    def _bring_up(**kw):
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=dev, **kw)
+            t = torch.zeros(1, device=dev)
+            dist.all_reduce(t)          # the communicator itself is created by the first collective
+            torch.cuda.synchronize()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        _bring_up()
     elif not args.no_train and args.precision == "bf16":
         # N = 1: a world-size-1 RCCL group, so that the DoRA step below goes through dist.init's path and
         # FlatGradBucket.all_reduce_mean issues a real ncclAllReduce on the 6.1 MB (tiny) / 10.8 MB (small) bucket --
         # `dora_step.split_ms.allreduce` is then a measured collective, not a skipped branch
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        _bring_up(rank=0, world_size=1)
 
     from gw_whisper_amd import ops, synth
     from gw_whisper_amd.encoder import WhisperConfig, WhisperEncoder

@@ -91,6 +91,11 @@ __global__ __launch_bounds__(256) void k_attn_rowdot(const unsigned short* __res
 }
 
 // ------------------------------------------------------------------------------------ dQ
+// L2Q (the training step: q in log2 units, ssc = 1): the row constants enter as the INITIAL ACCUMULATORS of the two
+// score-like products -- S' = q k - lse and dP' = dO v - D leave their MFMA chains ready, p = v_exp_f32(S') and
+// dS = p dP' are two vector instructions per element (round 3: fma, exp, subtract, two multiplies and a key-mask
+// select); the 1 / log2(e) of dS is applied once to the finished dQ; only the ragged last key tile masks its keys.
+template <bool L2Q>
 __global__ __launch_bounds__(256, GWW_ATTBWD_DQ_WAVES) void k_attn_bwd_dq(const unsigned short* __restrict__ qkv,
                                                         const unsigned short* __restrict__ dctx,
                                                         const float* __restrict__ lse,
@@ -105,7 +110,10 @@ __global__ __launch_bounds__(256, GWW_ATTBWD_DQ_WAVES) void k_attn_bwd_dq(const 
   auto Vr = [&](int buf) -> unsigned char* { return lds + (buf * 3 + 2) * TILE_BYTES; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qt = blockIdx.x % q_tiles, bh = blockIdx.x / q_tiles;
+  // XCD-aware work order (attention.hip): the query tiles of one (b, h) stream the same K / V -- keep them on one XCD
+  const unsigned nblk = gridDim.x, per = nblk >> 3;
+  const unsigned wid = blockIdx.x < 8 * per ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
+  const int qt = wid % q_tiles, bh = wid / q_tiles;
   const int b = bh / H, h = bh - b * H, d = H * DH;
   const long rs = 3L * d;
   const unsigned short* base = qkv + (long)b * T * rs;
@@ -171,17 +179,20 @@ __global__ __launch_bounds__(256, GWW_ATTBWD_DQ_WAVES) void k_attn_bwd_dq(const 
     for (int j = 0; j < 16; ++j) dqt[n][j] = 0.f;
 
   const int n_kt = (T + KB - 1) / KB;
+  // the row constants as accumulator start values (the query sits on the lane: all 16 registers hold the same value)
+  f32x16 c_lse, c_D;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { c_lse[j] = L2Q ? -lse_q : 0.f; c_D[j] = L2Q ? -D_q : 0.f; }
   gload(0);
   lstore(0);
   __syncthreads();
   for (int kt = 0; kt < n_kt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < n_kt) gload(kt + 1);
+    const bool mask_tile = kt == n_kt - 1 && (T % KB) != 0;   // wave-uniform
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      f32x16 st, dpt;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) { st[j] = 0.f; dpt[j] = 0.f; }
+      f32x16 st = c_lse, dpt = c_D;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kr(buf) + row_off(32 * g + r, 2 * s + hh));
@@ -190,11 +201,24 @@ __global__ __launch_bounds__(256, GWW_ATTBWD_DQ_WAVES) void k_attn_bwd_dq(const 
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dpt, 0, 0, 0);
       }
       // dS^T = P^T * (dP^T - D), P^T = exp(S^T - LSE); keys >= T contribute nothing
+      if constexpr (L2Q) {
+        if (mask_tile) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int key = kt * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
-        const float p = (key < T) ? __builtin_amdgcn_exp2f(fmaf(st[j], ssc, -lse_q)) : 0.f;
-        st[j] = p * (dpt[j] - D_q) * gsc;
+          for (int j = 0; j < 16; ++j) {
+            const int key = kt * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
+            st[j] = (key < T) ? __builtin_amdgcn_exp2f(st[j]) * dpt[j] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) st[j] = __builtin_amdgcn_exp2f(st[j]) * dpt[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int key = kt * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
+          const float p = (key < T) ? __builtin_amdgcn_exp2f(fmaf(st[j], ssc, -lse_q)) : 0.f;
+          st[j] = p * (dpt[j] - D_q);
+        }
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -213,13 +237,16 @@ __global__ __launch_bounds__(256, GWW_ATTBWD_DQ_WAVES) void k_attn_bwd_dq(const 
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        u32x2 o = {pack2bf(dqt[n][4 * c], dqt[n][4 * c + 1]), pack2bf(dqt[n][4 * c + 2], dqt[n][4 * c + 3])};
+        u32x2 o = {pack2bf(dqt[n][4 * c] * gsc, dqt[n][4 * c + 1] * gsc), pack2bf(dqt[n][4 * c + 2] * gsc, dqt[n][4 * c + 3] * gsc)};
         *reinterpret_cast<u32x2*>(orow + 32 * n + 8 * c + 4 * hh) = o;
       }
   }
 }
 
 // ------------------------------------------------------------------------------------ dK, dV
+// L2Q: -lse log2(e) and -D of the tile's 64 queries are staged NEGATED and read from LDS straight into the accumulators of
+// S and dP (the query rows sit in the registers here); dS = p dP' without its 1 / log2(e), which the finished dK gets once.
+template <bool L2Q>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* __restrict__ qkv,
                                                          const unsigned short* __restrict__ dctx,
                                                          const float* __restrict__ lse,
@@ -237,7 +264,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
   auto Ls = [&](int buf) -> float* { return reinterpret_cast<float*>(lds + buf * STAGE + 4 * TILE_BYTES); };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ktile = blockIdx.x % k_tiles, bh = blockIdx.x / k_tiles;
+  const unsigned nblk = gridDim.x, per = nblk >> 3;   // XCD-aware order: the key tiles of one (b, h) stream the same Q / dO
+  const unsigned wid = blockIdx.x < 8 * per ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
+  const int ktile = wid % k_tiles, bh = wid / k_tiles;
   const int b = bh / H, h = bh - b * H, d = H * DH;
   const long rs = 3L * d;
   const unsigned short* base = qkv + (long)b * T * rs;
@@ -277,8 +306,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
     }
     if (tid < 128) {
       const int q = qt * KB + (tid & 63);
-      // queries past T get LSE = +inf (P = 0) and D = 0
+      // queries past T get LSE = +inf (P = 0) and D = 0; L2Q: both negated (accumulator start values)
       rl = (tid < 64) ? (q < T ? lsep[q] * kLog2e : INFINITY) : (q < T ? Dp[q] : 0.f);
+      if constexpr (L2Q) rl = -rl;
     }
   };
   auto lstore = [&](int buf) {
@@ -317,9 +347,19 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       // S[q][key], dP[q][key]: rows q = 32 g + (reg&3) + 8 (reg>>2) + 4 hh in registers, key on the lane
-      f32x16 sm, dpm;
+      f32x16 sm, dpm, ds;
+      if constexpr (L2Q) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) { sm[j] = 0.f; dpm[j] = 0.f; }
+        for (int c = 0; c < 4; ++c) {   // -lse, -D of the rows in registers 4 c .. 4 c + 3: the chains' start values
+          const float4 l4 = *reinterpret_cast<const float4*>(Ls(buf) + 32 * g + 8 * c + 4 * hh);
+          const float4 d4 = *reinterpret_cast<const float4*>(Ls(buf) + 64 + 32 * g + 8 * c + 4 * hh);
+          sm[4 * c] = l4.x; sm[4 * c + 1] = l4.y; sm[4 * c + 2] = l4.z; sm[4 * c + 3] = l4.w;
+          dpm[4 * c] = d4.x; dpm[4 * c + 1] = d4.y; dpm[4 * c + 2] = d4.z; dpm[4 * c + 3] = d4.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { sm[j] = 0.f; dpm[j] = 0.f; }
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qr(buf) + row_off(32 * g + r, 2 * s + hh));
@@ -327,17 +367,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
         sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], sm, 0, 0, 0);
         dpm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[s], dpm, 0, 0, 0);
       }
-      f32x16 ds;
+      if constexpr (L2Q) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 l4 = *reinterpret_cast<const float4*>(Ls(buf) + 32 * g + 8 * c + 4 * hh);
-        const float4 d4 = *reinterpret_cast<const float4*>(Ls(buf) + 64 + 32 * g + 8 * c + 4 * hh);
-        const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+        for (int j = 0; j < 16; ++j) {
+          sm[j] = __builtin_amdgcn_exp2f(sm[j]);
+          ds[j] = sm[j] * dpm[j];
+        }
+      } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sm[4 * c + e], ssc, -ll[e]));
-          sm[4 * c + e] = p;
-          ds[4 * c + e] = p * (dpm[4 * c + e] - dd[e]) * gsc;
+        for (int c = 0; c < 4; ++c) {
+          const float4 l4 = *reinterpret_cast<const float4*>(Ls(buf) + 32 * g + 8 * c + 4 * hh);
+          const float4 d4 = *reinterpret_cast<const float4*>(Ls(buf) + 64 + 32 * g + 8 * c + 4 * hh);
+          const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sm[4 * c + e], ssc, -ll[e]));
+            sm[4 * c + e] = p;
+            ds[4 * c + e] = p * (dpm[4 * c + e] - dd[e]);
+          }
         }
       }
 #pragma unroll
@@ -362,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        u32x2 ok = {pack2bf(dkt[n][4 * c], dkt[n][4 * c + 1]), pack2bf(dkt[n][4 * c + 2], dkt[n][4 * c + 3])};
+        u32x2 ok = {pack2bf(dkt[n][4 * c] * gsc, dkt[n][4 * c + 1] * gsc), pack2bf(dkt[n][4 * c + 2] * gsc, dkt[n][4 * c + 3] * gsc)};
         u32x2 ov = {pack2bf(dvt[n][4 * c], dvt[n][4 * c + 1]), pack2bf(dvt[n][4 * c + 2], dvt[n][4 * c + 3])};
         *reinterpret_cast<u32x2*>(krow + 32 * n + 8 * c + 4 * hh) = ok;
         *reinterpret_cast<u32x2*>(vrow + 32 * n + 8 * c + 4 * hh) = ov;
@@ -390,12 +437,15 @@ int launch_attention_bwd_bf16(const void* qkv, const void* ctx, const void* dctx
   const int tiles = (T + TB - 1) / TB;
   const long blocks = (long)tiles * B * H;
   GWW_REQUIRE(blocks < 2147483647L, "attention_bwd: grid too large");
-  hipLaunchKernelGGL(k_attn_bwd_dq, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)qkv,
-                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles, nz, ssc, gsc);
+#define GWW_ATTBWD_LAUNCH(L)                                                                                       \
+  hipLaunchKernelGGL(k_attn_bwd_dq<L>, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)qkv,          \
+                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles, nz, ssc, gsc);         \
+  GWW_LAUNCH_CHECK();                                                                                               \
+  hipLaunchKernelGGL(k_attn_bwd_dkv<L>, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)qkv,         \
+                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles, nz, ssc, gsc);         \
   GWW_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_attn_bwd_dkv, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)qkv,
-                     (const unsigned short*)dctx, lse, D, (unsigned short*)dqkv, T, H, tiles, nz, ssc, gsc);
-  GWW_LAUNCH_CHECK();
+  if (q_log2) { GWW_ATTBWD_LAUNCH(true) } else { GWW_ATTBWD_LAUNCH(false) }
+#undef GWW_ATTBWD_LAUNCH
   return GWW_OK;
 }
 

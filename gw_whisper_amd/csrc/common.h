@@ -140,7 +140,8 @@ int launch_gemm_bf16(const void* A, long lda, const void* W, const float* bias, 
                      const float* pos, void* C, long M, int N, int K, int epi, int rows_per_batch,
                      hipStream_t s, int rows_padded_256 = 0);
 int launch_gemm_bf16_v4(const void* A, long lda, const void* W, const float* bias, const float* resid, void* C, long M,
-                        int N, int K, int epi, hipStream_t s, int force_split = 0);
+                        int N, int K, int epi, hipStream_t s, int force_split = 0, const float* pos = nullptr,
+                        int rows_per_batch = 0, int n_real = 0, float* dump = nullptr);
 int launch_gemm_fulln(const void* A, long lda, const void* W, const float* bias, const float* pos, void* C,
                       long M, int N, int K, int epi, int rows_per_batch, hipStream_t s);
 int launch_gemm_f32(const float* A, long lda, const float* W, const float* bias, const float* resid,

@@ -130,7 +130,7 @@ extern "C" int gww_encoder_create(const gww_enc_cfg* cfg, gww_encoder** out) {
   // carve one allocation
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
-  const size_t o_c1w = take((size_t)d * kConv1Kpad * 2), o_c2w = take((size_t)d * 3 * d * 2);
+  const size_t o_c1w = take((size_t)d * kConv1Kpad * 2), o_c2w = take((size_t)((d + 255) / 256 * 256) * 3 * d * 2);   // rows d .. : zero padding (k_gemm_bf16_v4 takes N % 256 == 0)
   const size_t o_c1w32 = take((size_t)d * kConv1Kpad * 4), o_c2w32 = take((size_t)d * 3 * d * 4);
   const size_t o_c1wT = take((size_t)d * kConv1Kpad * 2), o_c2wT = take((size_t)d * 3 * d * 2);
   const size_t o_c1b = take(d * 4), o_c2b = take(d * 4), o_pos = take((size_t)T * d * 4);
@@ -290,6 +290,7 @@ static int pack_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_
                 "gww_encoder_set_weights: NULL global weight");
     GWW_TRY(pack(g->conv1_w, e->c1w, e->c1w32, d, C, 3, kConv1Kpad, 1.f));
     GWW_TRY(pack(g->conv2_w, e->c2w, e->c2w32, d, d, 3, 3 * d, 1.f));
+    if (d % 256 != 0) GWW_HIP(hipMemsetAsync(e->c2w + (size_t)d * 3 * d, 0, (size_t)((d + 255) / 256 * 256 - d) * 3 * d * 2, s));
     GWW_TRY(launch_transpose_bf16(e->c1w, e->c1wT, d, kConv1Kpad, s));
     GWW_TRY(launch_transpose_bf16(e->c2w, e->c2wT, d, 3 * d, s));
     GWW_TRY(launch_scale_copy(g->conv1_b, e->c1b, d, 1.f, s));
@@ -411,7 +412,7 @@ WsLayout ws_layout(const gww_enc_cfg& c, int B, int precision) {
   // unconditionally (rows past B*T are scratch); +512 covers conv2's remapped garbage rows
   const size_t Mp = ((size_t)B * T + 255) / 256 * 256 + 512;
   w.melT = take(((size_t)B * (Tin + 2) * C + kConv1Kpad) * es);
-  w.c1 = take((((size_t)B * (Tin + 2) + 255) / 256 * 256 + 2) * d * es);
+  w.c1 = take((((size_t)B * (Tin + 2) + 255) / 256 * 256 + 520) * d * es);   // (+ 520: conv2's 256-row panels read 2 * 255 + 3 rows past the last segment)
   w.x = take(Mp * d * 4);
   w.x2 = take(Mp * d * 4);      // ping-pong partner of x for the fused residual-add prologue
   w.h = take(Mp * d * es);      // LayerNorm output, or out_proj delta on the A-stationary path
@@ -536,7 +537,10 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   else
     TR(TR_CONV1, gemm(melT, C, e->c1w, e->c1w32, e->c1b, nullptr, nullptr, c1, (long)B * (Tin + 2), d, kConv1Kpad,
                       EPI_CONV1, Tin + 2));
-  if (bf && (d == 384 || d == 512) && !(generic_mask & 4))
+  if (bf && d % 128 == 0 && d <= 3072 && !(generic_mask & 4))   // the eight-phase 256 x 256 GEMM over overlapping rows (gemm_v4.hip)
+    TR(TR_CONV2, launch_gemm_bf16_v4(c1, 2L * d, e->c2w, e->c2b, nullptr, x, (long)B * (T + 1), (d + 255) / 256 * 256, 3 * d,
+                                     EPI_CONV2, s, 0, e->pos, T + 1, d, x + (((size_t)B * T + 255) / 256 * 256) * d));
+  else if (bf && (d == 384 || d == 512) && !(generic_mask & 1024))
     TR(TR_CONV2, launch_gemm_fulln(c1, 2L * d, e->c2w, e->c2b, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2, T + 1, s));
   else
     TR(TR_CONV2, gemm(c1, 2L * d, e->c2w, e->c2w32, e->c2b, nullptr, e->pos, x, (long)B * (T + 1), d, 3 * d, EPI_CONV2,
@@ -739,7 +743,7 @@ TrainWs train_ws(const gww_enc_cfg& c, int B) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
   w.melT = take(((size_t)B * (Tin + 2) * C + kConv1Kpad) * 2);
-  w.c1 = take((((size_t)B * (Tin + 2) + 255) / 256 * 256 + 2) * d * 2);
+  w.c1 = take((((size_t)B * (Tin + 2) + 255) / 256 * 256 + 520) * d * 2);
   w.h2 = take(Mp * d * 2);      // per-op path: LN2 output; fused path: out_proj delta (fwd), recomputed LN1 output (bwd)
   w.f1 = take(Mp * F * 2);      // per-op path: gelu(fc1); fused path: recomputed pre-GELU fc1 output (bwd)
   w.d2 = take(Mp * d * 2);      // fused path: the last layer's fc2 delta
@@ -802,7 +806,8 @@ extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int b
   if (train_fused(e->cfg)) {   // the inference stem kernels (A-stationary conv1, full-N conv2)
     GWW_TRY(launch_gemm_astat(melT, C, nullptr, nullptr, nullptr, nullptr, e->c1w, e->c1b, c1, (long)B * (Tin + 2), d,
                               kConv1Kpad, EPI_CONV1, Tin + 2, s));
-    GWW_TRY(launch_gemm_fulln(c1, 2L * d, e->c2w, e->c2b, e->pos, x_in(0), (long)B * (T + 1), d, 3 * d, EPI_CONV2, T + 1, s));
+    GWW_TRY(launch_gemm_bf16_v4(c1, 2L * d, e->c2w, e->c2b, nullptr, x_in(0), (long)B * (T + 1), (d + 255) / 256 * 256, 3 * d,
+                                EPI_CONV2, s, 0, e->pos, T + 1, d, (float*)h2));   // (h2 is idle here: the scratch row of the garbage rows)
   } else {
     GWW_TRY(launch_gemm_bf16(melT, C, e->c1w, e->c1b, nullptr, nullptr, c1, (long)B * (Tin + 2), d, kConv1Kpad, EPI_CONV1,
                              Tin + 2, s, 0));
@@ -828,10 +833,9 @@ extern "C" int gww_encoder_train_forward(gww_encoder* e, const float* mel, int b
       float* x_mid = (float*)(lb + sl.x_mid);
       void* z = lb + sl.z;
       if (l == 0) {
-        // layer 0: LayerNorm kernel + plain A-stationary q/k/v GEMM (at this batch the LayerNorm-fused variant is the
-        // slower one: 292 us against 41 + 112 us at 64 segments -- it re-reads the fp32 panel per n-split)
-        GWW_TRY(launch_layernorm(x_in(0), W.ln1w, W.ln1b, d1, 1, M, d, s));
-        GWW_TRY(launch_gemm_astat(d1, d, nullptr, nullptr, nullptr, nullptr, W.wqkv, W.bqkv16, qkv, M, 3 * d, d, EPI_BIAS, 0, s));
+        // layer 0: LN1 + q / k / v on the fused block's panel prologue + tail (k_mlp_fused<2, false>), as the inference
+        // forward does (round 3 ran the LayerNorm kernel + the plain A-stationary GEMM here: 41 + 112 us at 64 segments)
+        GWW_TRY(launch_lnqkv_fused(x_in(0), W.uqkv, W.cbqkv, W.wqkv_st, qkv, M, d, 3 * d, s));
       }
       if (pooled && l == L - 1) {
         // only the query tile that holds token T - 1 is needed (forward and backward): the other rows of ctx / lse stay

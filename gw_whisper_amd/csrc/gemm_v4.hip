@@ -90,12 +90,21 @@ template <int EPI>
 __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* __restrict__ A, long lda,
                                                          const unsigned short* __restrict__ W,
                                                          const float* __restrict__ bias, const float* resid,
-                                                         void* C, long M, int N, int K, int n_split, int tpi, int n_items) {
+                                                         void* C, long M, int N, int K, int n_split, int tpi, int n_items,
+                                                         const float* __restrict__ pos, int rows_per_batch, int n_real,
+                                                         float* dump) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF4 + BIAS4 * 4];
   float* lds_bias = reinterpret_cast<float*>(lds + 2 * BUF4);   // the whole bias vector (N <= BIAS4)
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* g_ptr;
-  constexpr bool BF16OUT = EPI != EPI_RESID;
+  // EPI_CONV2 (the stride-2 convolution of the stem as a GEMM over overlapping rows, HF:modeling_whisper.py:619-624):
+  // fp32 out = gelu(acc + bias) + pos[t], row m = b * rows_per_batch + t -> row b * (rows_per_batch - 1) + t, the
+  // per-segment garbage row t = rows_per_batch - 1 and the rows past M go to the scratch row `dump` (every store is
+  // issued: the ring waits count them); the weight panel is padded to N % 256 == 0 with zero rows, n_real = the true
+  // width -- a W half that is all padding gets no MFMAs and no stores
+  constexpr bool CONV2 = EPI == EPI_CONV2;
+  constexpr bool BF16OUT = EPI != EPI_RESID && !CONV2;
+  constexpr bool PRELOAD = EPI == EPI_RESID;
   unsigned short* __restrict__ const Cb = reinterpret_cast<unsigned short*>(C);
   float* const Cf = reinterpret_cast<float*>(C);   // (EPI_RESID: may alias resid)
   constexpr int SQ = BF16OUT ? 4 : 8;              // stores per thread and output QUADRANT
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
     ncol = split * tpi + nn_i;
   };
 
-  for (int i = tid; i < N; i += 512) lds_bias[i] = bias ? bias[i] : 0.f;
+  for (int i = tid; i < N; i += 512) lds_bias[i] = (bias && i < n_real) ? bias[i] : 0.f;
 
   // ---- LDS-DMA: half-tile h of an operand = 16 pieces of 8 rows; wave w requests pieces 2 w, 2 w + 1 (rows 16 w ..).
   // Lane l lands at row l >> 3, position l & 7 of its piece, which holds chunk (l & 7) ^ ((row >> 1) & 7) of that row.
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
   f32x4 acc[2][2][2][4];   // [A half][W half][m-tile][n-tile]
   // PRE (bf16 outputs): A0 of the NEXT k-tile is read in phase 3 of this one (fragment reads per phase 8 / 4 / 8 / 4 instead
   // of 12 / 4 / 8 / 0); the fp32-residual form has no 16 registers left for the second A0 set
-  constexpr bool PRE = BF16OUT;
+  constexpr bool PRE = BF16OUT;   // (conv2: its epilogue holds the position rows and the GELU results side by side -- no room for the second A0 set)
   // DEEP (with PRE): every half-tile is requested as early as its LDS slot allows -- two phases behind the slot's last read:
   // phase 0: W1(t+1), 1: A0(t+2), 2: W0(t+2), 3: A1(t+2) -- SIX phases (1.5 k-tiles) ahead of the first read, five half-tiles
   // in flight behind every wait (vmcnt(10)); the A panel comes from HBM, and the ring wait was where its latency showed
@@ -245,6 +254,33 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
             *reinterpret_cast<u32x4*>(Cb + (m - (lane & 15) + (jp >> 1) * 8 + (lane >> 3)) * N + cbase + (lane & 7) * 8) = o;
           else *reinterpret_cast<u32x4*>(Cb + m * N + col) = o;
         }
+      } else if constexpr (CONV2) {
+        // (a quadrant of padding columns -- cbase >= n_real -- still issues its stores, into the scratch row: the ring waits
+        // count SQ stores per quadrant; its columns are folded back into the row so that pos / C are never read or written
+        // past n_real)
+        const bool padq = cbase >= n_real;
+        const int cfold = padq ? cbase - (n_real - 64) : 0;
+        const unsigned mu = (unsigned)m, rpb = (unsigned)rows_per_batch;   // (M < 2^31 is checked at launch)
+        const unsigned b = mu / rpb;
+        const int t = (int)(mu - b * rpb);
+        const bool live = m < M && t < rows_per_batch - 1 && !padq;
+        float* const orow = live ? Cf + ((long)b * (rows_per_batch - 1) + t) * n_real : dump;
+        const float* prow = pos + (long)(live ? t : 0) * n_real;
+        const int col0 = cbase - cfold + (lane >> 4) * 4;
+        // the position rows are requested FIRST: the GELU arithmetic of the 16 values below (about 0.5 us) covers their
+        // wait, which -- loads retire in issue order -- is also a wait for the half-tiles requested before them
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {   // (two column tiles at a time: 8 registers of position values live, not 16)
+          f32x4 pv[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) pv[u] = *reinterpret_cast<const f32x4*>(prow + col0 + (jp + u) * 16);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const f32x4 a = acc[ah][wh][i][jp + u] + bvj[jp + u];
+            const f32x4 g = {gelu_fast(a[0]), gelu_fast(a[1]), gelu_fast(a[2]), gelu_fast(a[3])};
+            *reinterpret_cast<f32x4*>(orow + col0 + (jp + u) * 16) = g + pv[u];
+          }
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -255,7 +291,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
       }
     }
     if constexpr (!BF16OUT) {
-      if (pre && !(GWW_G4_ABL & 1)) {
+      if (PRELOAD && pre && !(GWW_G4_ABL & 1)) {
         preload_resid(ah_c, wh_c, m0n, nnn);
       } else {
 #pragma unroll
@@ -281,7 +317,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  } else if (GWW_G4_ABL & 1) {
+  } else if (!PRELOAD || (GWW_G4_ABL & 1)) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -353,14 +389,18 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
     auto mfma16 = [&](auto ah_c, auto wh_c, auto&& tail) {
       constexpr int AH = decltype(ah_c)::value, WH = decltype(wh_c)::value;
       constexpr int PH = AH == 0 ? (WH == 0 ? 0 : 3) : (WH == 0 ? 1 : 2);
+      // conv2 at d = 384: the second column tile's W1 half is zero padding -- its two phases keep their barriers and
+      // requests (the stream stays uniform) but issue no MFMAs
+      if (!(CONV2 && WH == 1 && ncolc * 256 + 128 >= n_real)) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[AH][WH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], AH ? af1[i][ks] : af0[PRE ? B : 0][i][ks],
-                                                                        acc[AH][WH][i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+              acc[AH][WH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], AH ? af1[i][ks] : af0[PRE ? B : 0][i][ks],
+                                                                          acc[AH][WH][i][j], 0, 0, 0);
+      }
       tail();
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -452,7 +492,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
       stage(ic<B>{}, ic<2>{}, wo2);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (B == 1) ring_wait(last, ic<3 * SQ>{});
-      else ring_wait(first, ic<(BF16OUT ? SQ : 0)>{});
+      else ring_wait(first, ic<(PRELOAD ? 0 : SQ)>{});
     }
     mid(ic<3>{});
     mfma16(ic<0>{}, ic<1>{}, [&]() {
@@ -490,11 +530,19 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
 // instead of the automatic choice -- an output element's accumulation order does not depend on it, which is what the
 // split-invariance test checks bit for bit
 int launch_gemm_bf16_v4(const void* A, long lda, const void* W, const float* bias, const float* resid, void* C, long M,
-                        int N, int K, int epi, hipStream_t s, int force_split) {
+                        int N, int K, int epi, hipStream_t s, int force_split, const float* pos, int rows_per_batch,
+                        int n_real, float* dump) {
   // (no lower bound on M: a segment's rows must not depend on how many segments share the launch -- the batch-independence
   // property the tests check bit for bit -- so the kernel choice may depend on N and K only)
   if (N % 256 != 0 || K % 128 != 0 || N > BIAS4 || M < 1) return -1;
-  if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID)) return -1;
+  if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_CONV2)) return -1;
+  if (epi == EPI_CONV2) {
+    GWW_REQUIRE(M < 2147483647L, "gemm_bf16_v4: conv2 row count too large");
+    GWW_REQUIRE(pos && rows_per_batch > 1 && n_real > 0 && n_real <= N && N - n_real < 256 && n_real % 128 == 0 && dump,
+                "gemm_bf16_v4: conv2 epilogue needs pos, rows_per_batch, n_real (N - 255 .. N, a multiple of 128) and a scratch row");
+  } else {
+    n_real = N;
+  }
   const long panels = cdiv(M, 256);
   const int tn = N / 256;
   // column splits: a split's W slice should sit in one XCD's 4-MB L2 beside the streaming A panels (<= 1.5 MB).  Among the
@@ -536,10 +584,11 @@ int launch_gemm_bf16_v4(const void* A, long lda, const void* W, const float* bia
 #define GWW_GEMM4_CASE(E)                                                                             \
   case E:                                                                                             \
     hipLaunchKernelGGL((k_gemm_bf16_v4<E>), grid, block, 0, s, (const unsigned short*)A, lda,         \
-                       (const unsigned short*)W, bias, resid, C, M, N, K, n_split, tpi, (int)n_items); \
+                       (const unsigned short*)W, bias, resid, C, M, N, K, n_split, tpi, (int)n_items, pos,     \
+                       rows_per_batch, n_real, dump);                                                     \
     break;
   switch (epi) {
-    GWW_GEMM4_CASE(EPI_BIAS) GWW_GEMM4_CASE(EPI_GELU) GWW_GEMM4_CASE(EPI_RESID)
+    GWW_GEMM4_CASE(EPI_BIAS) GWW_GEMM4_CASE(EPI_GELU) GWW_GEMM4_CASE(EPI_RESID) GWW_GEMM4_CASE(EPI_CONV2)
     default:
       return -1;
   }
@@ -555,7 +604,7 @@ extern "C" int gww_gemm_bf16_v4_split(const void* A, const void* W, const float*
   GWW_REQUIRE(epilogue >= 0 && epilogue <= 2, "gww_gemm_bf16_v4_split: epilogue must be 0, 1 or 2");
   GWW_REQUIRE(M % 256 == 0, "gww_gemm_bf16_v4_split: M must be a multiple of 256 (got %ld)", M);
   GWW_REQUIRE(epilogue != 2 || resid != nullptr, "gww_gemm_bf16_v4_split: residual epilogue needs resid");
-  const int rc = gww::launch_gemm_bf16_v4(A, K, W, bias, resid, C, M, N, K, epilogue, (hipStream_t)stream, n_split);
+  const int rc = gww::launch_gemm_bf16_v4(A, K, W, bias, resid, C, M, N, K, epilogue, (hipStream_t)stream, n_split, nullptr, 0, 0, nullptr);
   if (rc == -1) return gww::fail(GWW_ERR_ARG, "gww_gemm_bf16_v4_split: not a shape of the 256 x 256 x 64 kernel (N=%d K=%d)", N, K);
   return rc;
 }
