@@ -517,7 +517,7 @@ def main():
         extra["whisper_small_forward"] = {"batch": 64, "ms_per_batch": ms_s, "segments_per_s_per_gpu": 64 / ms_s * 1e3,
                                           "achieved_tflops_per_gpu": tf_s, "frac_of_bf16_mfma_peak": tf_s / MFMA_BF16_PEAK_TFLOPS,
                                           "workload": "BASELINE configs[2] / [4] encoder (per-op path: LayerNorm kernel + "
-                                                      "k_gemm_bf16_v4 + k_attention_w64_bf16)"}
+                                                      "k_gemm_bf16_v4 + k_attention_dma_bf16)"}
         del enc_s
         torch.cuda.empty_cache()
         # the parity gate itself: GWW_PREC_F32 (exact fp32 MFMA, 1/16 of the bf16 rate) -- the mode whose logits match

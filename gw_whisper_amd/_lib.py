@@ -119,6 +119,9 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "gww_qadapter_cnn_packed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "gww_qadapter_cnn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gww_qadapter_cnn_backward_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gww_qadapter_cnn_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 9),
     "gww_qadapter_cnn_pack_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gww_qadapter_cnn_forward_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
@@ -134,7 +137,7 @@ SIGNATURES = {
     "gww_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
 }
 
-ABI_VERSION = 105   # include/gww.h GWW_VERSION this binding was written against
+ABI_VERSION = 106   # include/gww.h GWW_VERSION this binding was written against
 
 _lib = None
 

@@ -197,6 +197,43 @@ class _AdapterTail(torch.autograd.Function):
         return d_y, d_scale, d_bias, d_gamma, d_beta, g_rest, None
 
 
+class _CnnFunction(torch.autograd.Function):
+    """``freq_adapter(qspec[:, None])[:, 0]`` with BOTH directions as HIP kernels (``gww_qadapter_cnn_forward_f32`` /
+    ``gww_qadapter_cnn_backward_f32``): the training step of the adapter (MLGWSC-1/train.py:494-504) makes no library
+    convolution call either.  The Q-scan map needs no gradient (the reference computes it under ``no_grad``, :139-141); the
+    forward saves only its input, the backward recomputes the activations."""
+
+    @staticmethod
+    def forward(ctx, adapter, qspec, w1, b1, w2, b2, w3, b3, w4, b4):
+        y = adapter.cnn_forward(qspec)
+        ctx.adapter = adapter
+        ctx.save_for_backward(qspec.detach().to(torch.float32).contiguous(), w2.detach(), w3.detach())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        qspec, w2, w3 = ctx.saved_tensors
+        ad = ctx.adapter
+        packed, ch = ad._packed_cnn()
+        B, H, W = qspec.shape
+        dev = qspec.device
+        c1, c2, c3 = ch
+        g = [torch.empty(s, dtype=torch.float32, device=dev) for s in
+             ((c1, 1, 3, 3), (c1,), (c2, c1, 3, 3), (c2,), (c3, c2, 3, 3), (c3,), (1, c3, 1, 1), (1,))]
+        need = lib().gww_qadapter_cnn_backward_workspace_bytes(B, H, W, c1, c2, c3)
+        ws = getattr(ad, "_cnn_bwd_ws", None)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = ad._cnn_bwd_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        dyc = dy.to(torch.float32).contiguous()
+        w2c, w3c = w2.to(torch.float32).contiguous(), w3.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            check(lib().gww_qadapter_cnn_backward_f32(qspec.data_ptr(), dyc.data_ptr(), B, H, W, packed.data_ptr(),
+                                                      w2c.data_ptr(), w3c.data_ptr(), c1, c2, c3, ws.data_ptr(), ws.numel(),
+                                                      *[t.data_ptr() for t in g], torch.cuda.current_stream().cuda_stream),
+                  "gww_qadapter_cnn_backward_f32")
+        return (None, None, *g)
+
+
 class QTransformAdapter(nn.Module):
     """The reference's Q-transform adapter, both variants, same constructor arguments, parameter names and forward:
 
@@ -252,9 +289,9 @@ class QTransformAdapter(nn.Module):
         m.load_state_dict(sd)
         return m
 
-    # ---- the CNN as HIP kernels (csrc/qadapter_cnn.hip): the inference path.  Training the adapter (MLGWSC-1/train.py:
-    # 494-504 trains it through the frozen encoder) keeps the torch.nn modules, whose autograd provides the weight / input
-    # gradients; both run the same parameters.
+    # ---- the CNN as HIP kernels (csrc/qadapter_cnn.hip), forward AND (round 4) backward: training the adapter
+    # (MLGWSC-1/train.py:494-504 trains it through the frozen encoder) goes through _CnnFunction; the torch.nn modules hold
+    # the parameters (state_dict names of the reference) and only run for channel widths / map sizes the kernels do not have.
     def _cnn_params(self):
         fa = self.freq_adapter
         return [fa[0].weight, fa[0].bias, fa[3].weight, fa[3].bias, fa[6].weight, fa[6].bias, fa[8].weight, fa[8].bias]
@@ -297,9 +334,10 @@ class QTransformAdapter(nn.Module):
         return y
 
     def _use_hip_cnn(self, x) -> bool:
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return False                       # training step: torch autograd through the torch.nn modules
         return self._packed_cnn()[0] is not None
+
+    def _cnn_needs_grad(self) -> bool:
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self._cnn_params())
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, D, _ = x.shape
@@ -311,7 +349,9 @@ class QTransformAdapter(nn.Module):
         for i in range(D):
             with torch.no_grad():
                 qspec = self.q_transform(x[:, i]).unsqueeze(1)        # [B, 1, F, T]  (plane chosen per call, per detector)
-            if hip_cnn:
+            if hip_cnn and self._cnn_needs_grad() and qspec.shape[-1] <= 512:
+                y = _CnnFunction.apply(self, qspec[:, 0], *self._cnn_params())   # HIP forward + HIP backward
+            elif hip_cnn and not self._cnn_needs_grad():
                 y = self.cnn_forward(qspec[:, 0])                     # three HIP launches, no library call
             else:
                 y = self.freq_adapter(qspec).squeeze(1)               # torch.nn (autograd for the adapter's training)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GWW_VERSION 105  /* 0.1.5: + gww_gemm_bf16_v4_split (explicit column split; no environment switch is read by the library any more); 0.1.4: gww_mlp_fused_bf16 / gww_attn_out_mlp_fused_bf16 with the q / k / v tail return x_next over x (x_out keeps x_new); 0.1.3: + gww_logmel_host_f32 (fork-safe CPU twin of the front end); 0.1.2: + whitening kernels, gww_qadapter_tail_f32, gww_attention_bwd_log2q_bf16, gww_lnqkv_fused_bf16, gww_attn_out_mlp_fused_bf16, gww_mlp_pack_op_bf16; the gww_mlp_pack_bf16 stream carries W1 / 8 and 8 W2 */
+#define GWW_VERSION 106  /* 0.1.6: + gww_qadapter_cnn_backward_f32 / _workspace_bytes (the Q-adapter CNN's backward as HIP kernels); 0.1.5: + gww_gemm_bf16_v4_split (explicit column split; no environment switch is read by the library any more); 0.1.4: gww_mlp_fused_bf16 / gww_attn_out_mlp_fused_bf16 with the q / k / v tail return x_next over x (x_out keeps x_new); 0.1.3: + gww_logmel_host_f32 (fork-safe CPU twin of the front end); 0.1.2: + whitening kernels, gww_qadapter_tail_f32, gww_attention_bwd_log2q_bf16, gww_lnqkv_fused_bf16, gww_attn_out_mlp_fused_bf16, gww_mlp_pack_op_bf16; the gww_mlp_pack_bf16 stream carries W1 / 8 and 8 W2 */
 
 #define GWW_OK 0
 #define GWW_ERR_ARG (-1)      /* bad argument (shape, null pointer, unsupported size) */
@@ -318,6 +318,18 @@ int gww_qadapter_cnn_pack_f32(const float* w1, const float* b1, const float* w2,
                               void* stream);
 int gww_qadapter_cnn_forward_f32(const float* qspec, int B, int H, int W, const void* packed, int c1, int c2, int c3,
                                  void* workspace, size_t workspace_bytes, float* y, void* stream);
+/* The CNN's BACKWARD (the adapter is trained through the frozen encoder, MLGWSC-1/train.py:494-504; replaces torch
+ * autograd through nn.Conv2d / nn.MaxPool2d, i.e. MIOpen): dy fp32 [B, H/4, W/4] = the gradient of
+ * gww_qadapter_cnn_forward_f32's y -> the gradients of the eight torch parameters in their torch shapes (fp32, overwritten):
+ * dw1 [c1,1,3,3] db1 [c1] dw2 [c2,c1,3,3] db2 [c2] dw3 [c3,c2,3,3] db3 [c3] dw4 [1,c3,1,1] db4 [1].  `packed` is the
+ * forward's blob, w2 / w3 the raw fp32 parameters (packed here, transposed, for the data gradients).  Nothing was saved by
+ * the forward: the activations are recomputed.  The Q-scan input needs no gradient (the reference computes it under
+ * no_grad).  W <= 512. */
+size_t gww_qadapter_cnn_backward_workspace_bytes(int B, int H, int W, int c1, int c2, int c3);
+int gww_qadapter_cnn_backward_f32(const float* qspec, const float* dy, int B, int H, int W, const void* packed,
+                                  const float* w2, const float* w3, int c1, int c2, int c3, void* workspace,
+                                  size_t workspace_bytes, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
+                                  float* db3, float* dw4, float* db4, void* stream);
 /* Whitening of the search pipeline's strain (MLGWSC-1/inference.py:56-137 -> PyCBC 2.4.0 TimeSeries.psd / welch /
  * inverse_spectrum_truncation; PARITY UNPINNED -- PyCBC is not installed, the kernels follow oracle/whiten.py).
  * gww_welch_power_f32: |rDFT|^2 * scale of the windowed Welch segments from their (re, im) rows (a gww_gemm_f32 against
