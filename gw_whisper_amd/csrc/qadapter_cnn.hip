@@ -452,6 +452,11 @@ __global__ __launch_bounds__(256) void k_qcnn_conv1_bwd(const float* __restrict_
     }
   }
   const float* gp = da + (((long)b * Hp + py) * Wp + px) * C1;
+  // per-workgroup sums in LDS first: every workgroup adds into the SAME 10 C1 global words, and atomics on one address
+  // serialise at the memory side (one add per wave and value -- 5 M adds on 320 addresses -- took 1.5 ms)
+  __shared__ float red[C1 * 10];
+  for (int i = threadIdx.x; i < C1 * 10; i += 256) red[i] = 0.f;
+  __syncthreads();
   for (int c = 0; c < C1; ++c) {
     float v[4];
 #pragma unroll
@@ -480,11 +485,22 @@ __global__ __launch_bounds__(256) void k_qcnn_conv1_bwd(const float* __restrict_
         contrib[ky * 3 + kx] = g * sel;
       }
     contrib[9] = g;
+    // sums over the 16 lanes of a DPP row (four butterfly steps on the vector ALU; __shfl_xor is an LDS round trip per step
+    // and made this kernel the most expensive of the whole training step), then one atomic per row and value
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
-      const float sum = wave_sum(contrib[k]);
-      if ((threadIdx.x & 63) == 0 && sum != 0.f) atomicAdd(k < 9 ? dw + c * 9 + k : db + c, sum);
+      float v2 = contrib[k];
+      v2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v2), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+      v2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v2), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+      v2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v2), 0x141, 0xF, 0xF, true));   // row_half_mirror
+      v2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v2), 0x140, 0xF, 0xF, true));   // row_mirror
+      if ((threadIdx.x & 15) == 0 && v2 != 0.f) atomicAdd(&red[c * 10 + k], v2);   // LDS
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C1 * 10; i += 256) {
+    const int c = i / 10, k = i - 10 * c;
+    if (red[i] != 0.f) atomicAdd(k < 9 ? dw + c * 9 + k : db + c, red[i]);
   }
 }
 
