@@ -572,6 +572,7 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
   const int r = lane & 31, hh = lane >> 5;
   const int q_row = qt * (NW * 32) + wave * 32 + r;
   const int q_ld = q_row < T ? q_row : T - 1;
+  const bool wave_live = qt * (NW * 32) + wave_u * 32 < T;   // wave-uniform
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + (long)q_ld * row_stride + 16 * s + 8 * hh);
@@ -636,6 +637,11 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
     constexpr int BUF = decltype(buf_c)::value;
     constexpr bool FIRST = decltype(first_c)::value, MASKED = decltype(masked_c)::value;
     if (kt + 1 < n_kt) dma(kt + 1, std::integral_constant<int, BUF ^ 1>{});
+    // Work that cannot contribute is skipped (wave-uniform tests; T = 1500: 2 % + 2 % of the launch): a wave whose 32 query
+    // rows all lie past T - 1 (the last query tile's tail) only requests its pieces and joins the barrier; the ragged last
+    // key tile computes its second key half only if a valid key lies in it (1500 = 23 x 64 + 28: it does not)
+    const bool g1_live = !MASKED || (T - kt * KB) > 32;
+    if (wave_live) {
     f32x16 st[2];
     auto scores = [&]() {
 #pragma unroll
@@ -643,6 +649,11 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
         f32x16 z;
 #pragma unroll
         for (int j = 0; j < 16; ++j) z[j] = 0.f;
+        if (MASKED && g == 1 && !g1_live) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) st[1][j] = -INFINITY;
+          continue;
+        }
         if constexpr (FIRST) st[g] = z;
         else st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, mref, z, 0, 0, 0);
 #pragma unroll
@@ -720,6 +731,7 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
     if constexpr (!MSUM) l_run += ps;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
+      if (MASKED && g == 1 && !g1_live) continue;   // (its probabilities are exp2(-inf) = 0)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 pf = cvt8(st[g], 8 * s);
@@ -736,6 +748,7 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
         }
       }
     }
+    }   // wave_live
     __syncthreads();   // vmcnt(0): this wave's pieces of tile kt + 1 have landed; barrier: everybody's have
   };
   using P0 = std::integral_constant<int, 0>;

@@ -144,6 +144,16 @@ def build_model(args, device):
 
 
 # ---------------------------------------------------------------------------------------------- search
+def gather_shards(trig, vals, world):
+    """Every rank's (triggers, per-batch scores) of ONE segment on every rank, in window order: the shards are contiguous,
+    batch-aligned window ranges in rank order (``inference.shard_windows``), so concatenating them in rank order restores
+    the single-GPU run's lists.  One object collective per segment, no tensor collective on the data path."""
+    import torch.distributed as dist
+    parts = [None] * world
+    dist.all_gather_object(parts, (trig, vals))
+    return [x for p in parts for x in p[0]], [v for p in parts for v in p[1]]
+
+
 def get_triggers(args, device, rank, world):
     """``get_triggers`` of the reference (inference.py:492-590): every segment, longest first; each rank evaluates its
     batch-aligned shard of the segment's windows and rank 0 receives all triggers."""
@@ -174,10 +184,7 @@ def get_triggers(args, device, rank, world):
             import torch.distributed as dist
             trig, vals = inf.evaluate_slices(slicer, network, trigger_threshold=args.trigger_threshold,
                                              batch_size=args.batch_size, window_range=(w0, w1))
-            parts = [None] * world
-            dist.all_gather_object(parts, (trig, vals))
-            trig = [x for p in parts for x in p[0]]           # shards are contiguous and in rank order
-            vals = [v for p in parts for v in p[1]]
+            trig, vals = gather_shards(trig, vals, world)
             if rank == 0:                                     # the gathered scores go back to rank 0's GPU to be clustered
                 full = torch.from_numpy(np.concatenate(vals).astype(np.float32)).to(device) if vals else torch.empty(0, device=device)
                 clusters[key] = inf.cluster_triggers_device(slicer.times(0, len(slicer)), full, args.trigger_threshold,

@@ -4,6 +4,7 @@ gradient bucket all-reduce used for DoRA + head gradients
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
@@ -196,3 +197,60 @@ def test_single_process_bucket_needs_no_group():
     assert torch.equal(bucket.flat, ref)
     bucket.all_reduce_mean(1, n_local=4)
     torch.testing.assert_close(bucket.flat, ref)
+
+
+def _search_worker(rank, world, port, tmp):
+    """One rank of the sharded search: scores of its batch-aligned window range (a deterministic function of the window
+    index stands in for the network -- the data path has no collective), thresholded as evaluate_slices does, gathered by
+    harness/run_inference.py's gather_shards over a real 2-process group."""
+    import importlib.util
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from gw_whisper_amd import inference as inf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_inference", os.path.join(root, "harness", "run_inference.py"))
+    ri = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ri)
+    n_win, batch, thr = 1003, 64, 0.2
+    scores = _fake_scores(n_win)
+    times = 1.0e9 + 0.1 * np.arange(n_win)
+    w0, w1 = inf.shard_windows(n_win, rank, world, batch)
+    mine = scores[w0:w1]
+    trig = [[float(times[w0 + i]), float(v)] for i, v in enumerate(mine) if v > thr]
+    vals = [mine[i:i + batch] for i in range(0, len(mine), batch)]
+    trig, vals = ri.gather_shards(trig, vals, world)
+    if rank == 0:
+        np.save(os.path.join(tmp, "trig.npy"), np.array(trig))
+        np.save(os.path.join(tmp, "vals.npy"), np.concatenate(vals))
+        t, v, var = inf.get_clusters({"seg": trig}, 0.35)
+        np.save(os.path.join(tmp, "clusters.npy"), np.stack([t, v, var]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _fake_scores(n):
+    rng = np.random.default_rng(42)
+    s = rng.random(n).astype(np.float32) * 0.25          # mostly below the threshold ...
+    for c in (40, 41, 42, 500, 777, 778, 1000):           # ... with a few bursts, one straddling the shard boundary region
+        s[c] = 0.9
+    s[510:515] = 0.6
+    return s
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_sharded_search_gathers_to_the_single_rank_result(tmp_path):
+    """SURVEY.md section 8e, inference: replicas over batch-aligned window shards, results gathered in rank order, clustered
+    once -- two gloo ranks give the triggers, the per-window scores and the clusters of the unsharded run, bit for bit."""
+    from gw_whisper_amd import inference as inf
+    port = _free_port()
+    mp.spawn(_search_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    n_win, thr = 1003, 0.2
+    scores = _fake_scores(n_win)
+    times = 1.0e9 + 0.1 * np.arange(n_win)
+    ref_trig = [[float(times[i]), float(v)] for i, v in enumerate(scores) if v > thr]
+    np.testing.assert_array_equal(np.load(tmp_path / "trig.npy"), np.array(ref_trig))
+    np.testing.assert_array_equal(np.load(tmp_path / "vals.npy"), scores)
+    t, v, var = inf.get_clusters({"seg": ref_trig}, 0.35)
+    np.testing.assert_array_equal(np.load(tmp_path / "clusters.npy"), np.stack([t, v, var]))
+    assert len(t) >= 4
+
