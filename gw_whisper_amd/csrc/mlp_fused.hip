@@ -75,6 +75,14 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #ifndef GWW_MF_DMAGAP
 #define GWW_MF_DMAGAP 1   // (with SCHED) DMA pieces of a riding tile in the gaps the GELU schedule leaves empty (0: one per step)
 #endif
+#ifndef GWW_MF_TAIL2
+#define GWW_MF_TAIL2 0   // 1 (round 4 experiment, tools/mlp_exp2.py TAIL2=1): the q / k / v tail as 64-column CHUNKS of three
+                         // fc1-format tiles, software-pipelined like the main loop -- the pack / LDS transpose / stores of chunk
+                         // c - 1 and the bias preload of chunk c + 1 ride in the MFMA gaps of chunk c.  Correct (the fp64 tests
+                         // pass on it) and NOT faster: 1.565 against 1.556 ms (profiles/r04_mlp_tail2.md) -- the epilogues it
+                         // hides were already overlapping the tail's real bound, the in-order vmcnt queue behind its output
+                         // stores -- and six more spilled registers.  0 (shipped): round 3's tail, n-tiles of 128 columns.
+#endif
 #ifndef GWW_MF_NORM
 #define GWW_MF_NORM 1   // 1: the A operand is normalised once per panel, a^ = bf16((a - mean') rstd), so the fc1 / q,k,v outputs need
                         // only + cb (0: round 1's per-value LayerNorm algebra rstd (acc - mean' u) + cb: two more VALU
@@ -965,7 +973,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   act_piece(0, b >> 1, 12); act_piece(0, b >> 1, 13); act_piece(0, b >> 1, 14); act_piece(0, b >> 1, 15);
   run_tile(MF_FL<9>{}, I1{}, I1{}, I0{}, IM{}, 0, 1, IM{}, 0, I1{});
   run_tile(MF_FL<10>{}, I1{}, I1{}, I1{}, IM{}, 0, 1, IM{}, 0, I1{});
-  run_tile(MF_FL<11>{}, I1{}, I1{}, I2{}, IM{}, 0, QKV ? 2 : 1, IM{}, 0, I1{});
+  run_tile(MF_FL<11>{}, I1{}, I1{}, I2{}, IM{}, 0, QKV ? (GWW_MF_TAIL2 ? 0 : 2) : 1, IM{}, 0, I1{});
 
   MSTAMP(4);
   if (GWW_MF_SCHED)   // asm MFMAs -> accumulator reads of the epilogue (as above); the operands keep the reads behind the pad
@@ -1116,6 +1124,166 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     __builtin_amdgcn_s_barrier();     // everybody's pieces visible
 
     MSTAMP(5);
+#if GWW_MF_TAIL2
+    // ---- second GEMM: qkv[32 rows, NQ] = LN1(x_next) Wqkv'^T as NQ / 64 column CHUNKS of three fc1-format tiles
+    // ([64 n][128 k], gww_mlp_pack_bf16).  Chunk c accumulates into the accumulator pair sacc[2 (c & 1)], [.. + 1] (preloaded with
+    // its folded bias); in the MFMA gaps of its 48 MFMAs ride, for the OTHER pair: the epilogue of chunk c - 1 (gaps 4 .. 11:
+    // pack + ds_write_b64 of the eight 4-column pieces; 22 .. 25: the four transposed row reads; 37 .. 40: the four 16-byte
+    // stores, behind the tile's LDS-DMA pieces) and the bias preload of chunk c + 1 (gaps 12 .. 19).  Nothing of a chunk's
+    // epilogue is in the open any more except the last one's.
+    // vmcnt: a chunk's four stores are issued in its third tile BEHIND that tile's four DMA pieces, so for the ring waits
+    // at the top of the next chunk's first and second tile they are younger than the awaited pieces and may stay in
+    // flight (+ 4); at the third tile they are older and long retired.
+    {
+    const int nchunks = NQ / 64;
+    u32x4 tq[4];                      // the four transposed row pieces of the chunk being stored
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tq[i] = u32x4{0u, 0u, 0u, 0u};
+    auto q_preload = [&](int t, int chunk, int q) {   // folded bias of chunk `chunk` -> accumulator sacc[t], registers 4 q ..
+      const float4 bv = *reinterpret_cast<const float4*>(lds_qcb + 64 * chunk + 32 * (t & 1) + 8 * q + 4 * hh);
+      sacc[t][4 * q] = bv.x; sacc[t][4 * q + 1] = bv.y; sacc[t][4 * q + 2] = bv.z; sacc[t][4 * q + 3] = bv.w;
+    };
+    // one gap of the ride: G = 0 .. 47 within the chunk; Q = the pair that rides (the other one), chunk = the chunk being computed
+    auto q_ride = [&](auto q_c, auto g_c, int chunk, auto mode_c) {
+      constexpr int Q = decltype(q_c)::value, G = decltype(g_c)::value, RM = decltype(mode_c)::value;   // 1: epilogue + preload, 2: preload only
+      if constexpr (RM == 1 && G >= 4 && G < 12) {
+        constexpr int tt = (G - 4) >> 2, cc = (G - 4) & 3;
+        const f32x16& a = sacc[2 * Q + tt];
+        u32x2 o = {pack2bf(a[4 * cc], a[4 * cc + 1]), pack2bf(a[4 * cc + 2], a[4 * cc + 3])};
+        *reinterpret_cast<u32x2*>(slice + r * MF_SLICE_STRIDE + (32 * tt + 8 * cc + 4 * hh) * 2) = o;
+      }
+      if constexpr (RM >= 1 && G >= 12 && G < 20) {
+        if (chunk + 1 < nchunks) q_preload(2 * Q + ((G - 12) >> 2), chunk + 1, (G - 12) & 3);
+      }
+      if constexpr (RM == 1 && G >= 22 && G < 26) {
+        tq[G - 22] = *reinterpret_cast<const u32x4*>(slice + (8 * (G - 22) + crow) * MF_SLICE_STRIDE + cchunk * 16);
+        asm volatile("" : "+v"(tq[G - 22]));
+      }
+      if constexpr (RM == 1 && G >= 37 && G < 41) {
+        const long orow = m_base + 8 * (G - 37) + crow;
+        if (!(GWW_MF_ABL & 1))
+          __builtin_nontemporal_store(tq[G - 37], reinterpret_cast<u32x4*>(q_out + orow * NQ + (chunk - 1) * 64 + 8 * cchunk));
+      }
+    };
+    // one tile of the tail: FLAT = tile index within the tail (its ring stage follows), PAR = chunk parity, IDX3 = tile of the
+    // chunk, RM = what rides (0 nothing), EXTRA = stores the ring wait may leave in flight, NOWAIT = no ring wait (behind the seam)
+    auto run_qtile = [&](auto flat_c, auto par_c, auto idx3_c, auto mode_c, int chunk, auto extra_c, auto nowait_c) {
+      constexpr int FLAT = decltype(flat_c)::value, PAR = decltype(par_c)::value, IDX3 = decltype(idx3_c)::value;
+      constexpr int RM = decltype(mode_c)::value, EXTRA = decltype(extra_c)::value;
+      constexpr bool NOWAIT = decltype(nowait_c)::value != 0;
+      constexpr int ST = MF_NST == 4 ? ((FLAT + OP_TILES) & 3) : -1;   // (6 F / 64 MLP tiles in front: a multiple of 4)
+      if (ST >= 0) stage = ST;
+      if (!(GWW_MF_ABL & 4)) {
+        if (!NOWAIT) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + ((GWW_MF_ABL & 3) ? 0 : EXTRA)>();
+      }
+      if (!(GWW_MF_ABL & 8)) __builtin_amdgcn_s_barrier();
+      TSTAMP(6);
+      const int dma_tile = it + MF_AHEAD < total ? it + MF_AHEAD : total - 1;
+      const int dma_stage = stage + MF_AHEAD >= MF_NST ? stage + MF_AHEAD - MF_NST : stage + MF_AHEAD;
+      const int stage_next = stage + 1 == MF_NST ? 0 : stage + 1;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        bf16x8(&cur)[4] = wf[sub & 1];
+        bf16x8(&nxt)[4] = wf[(sub + 1) & 1];
+        const unsigned char* Wn = lds + (sub == 3 ? stage_next : stage) * MF_TILE;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int tl = u & 1, ks = 2 * sub + (u >> 1);
+          asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[2 * PAR + tl]) : "v"(cur[u]), "v"(af[8 * IDX3 + ks]));
+          if (u < 3) asm volatile("" : "+v"(cur[u + 1]));
+          else if (sub < 3) asm volatile("" : "+v"(nxt[0]));
+          {
+            const int off = sub == 3 ? first_off(0, u) : (u & 1) * 8192 + off1[2 * (sub + 1) + (u >> 1)];
+            nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + off);
+          }
+          if constexpr (RM != 0) {
+            if (sub == 0 && u == 0) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 0>{}, chunk, mode_c);
+            else if (sub == 0 && u == 1) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 1>{}, chunk, mode_c);
+            else if (sub == 0 && u == 2) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 2>{}, chunk, mode_c);
+            else if (sub == 0 && u == 3) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 3>{}, chunk, mode_c);
+            else if (sub == 1 && u == 0) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 4>{}, chunk, mode_c);
+            else if (sub == 1 && u == 1) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 5>{}, chunk, mode_c);
+            else if (sub == 1 && u == 2) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 6>{}, chunk, mode_c);
+            else if (sub == 1 && u == 3) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 7>{}, chunk, mode_c);
+            else if (sub == 2 && u == 0) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 8>{}, chunk, mode_c);
+            else if (sub == 2 && u == 1) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 9>{}, chunk, mode_c);
+            else if (sub == 2 && u == 2) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 10>{}, chunk, mode_c);
+            else if (sub == 2 && u == 3) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 11>{}, chunk, mode_c);
+            else if (sub == 3 && u == 0) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 12>{}, chunk, mode_c);
+            else if (sub == 3 && u == 1) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 13>{}, chunk, mode_c);
+            else if (sub == 3 && u == 2) q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 14>{}, chunk, mode_c);
+            else q_ride(MF_FL<1 - PAR>{}, MF_FL<16 * IDX3 + 15>{}, chunk, mode_c);
+          }
+          // the tile's four LDS-DMA pieces: in the gaps the main loop uses (IDX3 0: 9 .. 12, 1: 5 .. 8, 2: 1 .. 4)
+          if (!(GWW_MF_ABL & 4)) {
+            const int piece = 4 * sub + u - (9 - 4 * IDX3);
+            if (piece >= 0 && piece < 4) issue_piece(dma_tile, dma_stage, piece);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stage = stage_next;
+      ++it;
+      TSTAMP(7);
+    };
+    using NW = std::conditional_t<LNQ || (GWW_MF_ABL & 32), I0, I1>;   // behind the seam the first two tiles have landed (above)
+    if (LNQ) {   // first-step fragments of the first tile (the MLP stream's last tile prefetches them otherwise)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wf[0][u] = *reinterpret_cast<const bf16x8*>(lds + stage * MF_TILE + first_off(0, u));
+    }
+    // bias of chunk 0 (in the open, once per panel)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) q_preload(t, 0, q);
+    // chunk 0: nothing to store yet; the bias of chunk 1 rides
+    run_qtile(MF_FL<0>{}, I0{}, I0{}, I2{}, 0, I0{}, NW{});
+    run_qtile(MF_FL<1>{}, I0{}, I1{}, I2{}, 0, I0{}, NW{});
+    run_qtile(MF_FL<2>{}, I0{}, I2{}, I2{}, 0, I0{}, I0{});
+    // chunk 1: epilogue of chunk 0 rides (no stores of an earlier chunk in the queue yet)
+    run_qtile(MF_FL<3>{}, I1{}, I0{}, I1{}, 1, I0{}, I0{});
+    run_qtile(MF_FL<4>{}, I1{}, I1{}, I1{}, 1, I0{}, I0{});
+    run_qtile(MF_FL<5>{}, I1{}, I2{}, I1{}, 1, I0{}, I0{});
+    using I4 = std::integral_constant<int, 4>;
+    for (int c = 2; c < nchunks; c += 4) {
+      run_qtile(MF_FL<6>{}, I0{}, I0{}, I1{}, c, I4{}, I0{});
+      run_qtile(MF_FL<7>{}, I0{}, I1{}, I1{}, c, I4{}, I0{});
+      run_qtile(MF_FL<8>{}, I0{}, I2{}, I1{}, c, I0{}, I0{});
+      run_qtile(MF_FL<9>{}, I1{}, I0{}, I1{}, c + 1, I4{}, I0{});
+      run_qtile(MF_FL<10>{}, I1{}, I1{}, I1{}, c + 1, I4{}, I0{});
+      run_qtile(MF_FL<11>{}, I1{}, I2{}, I1{}, c + 1, I0{}, I0{});
+      run_qtile(MF_FL<12>{}, I0{}, I0{}, I1{}, c + 2, I4{}, I0{});
+      run_qtile(MF_FL<13>{}, I0{}, I1{}, I1{}, c + 2, I4{}, I0{});
+      run_qtile(MF_FL<14>{}, I0{}, I2{}, I1{}, c + 2, I0{}, I0{});
+      run_qtile(MF_FL<15>{}, I1{}, I0{}, I1{}, c + 3, I4{}, I0{});
+      run_qtile(MF_FL<16>{}, I1{}, I1{}, I1{}, c + 3, I4{}, I0{});
+      run_qtile(MF_FL<17>{}, I1{}, I2{}, I1{}, c + 3, I0{}, I0{});
+    }
+    // the last chunk's epilogue, in the open (its pair: parity of nchunks - 1 = 1)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(sacc[2]), "+v"(sacc[3]));   // asm MFMA -> VALU read
+    if (!(GWW_MF_ABL & 2)) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const f32x16& a = sacc[2 + tt];
+          u32x2 o = {pack2bf(a[4 * cc], a[4 * cc + 1]), pack2bf(a[4 * cc + 2], a[4 * cc + 3])};
+          *reinterpret_cast<u32x2*>(slice + r * MF_SLICE_STRIDE + (32 * tt + 8 * cc + 4 * hh) * 2) = o;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4 u = *reinterpret_cast<const u32x4*>(slice + (8 * i + crow) * MF_SLICE_STRIDE + cchunk * 16);
+        const long orow = m_base + 8 * i + crow;
+        if (GWW_MF_ABL & 1) { asm volatile("" :: "v"(u)); continue; }
+        __builtin_nontemporal_store(u, reinterpret_cast<u32x4*>(q_out + orow * NQ + (nchunks - 1) * 64 + 8 * cchunk));
+      }
+    }
+    // the ring's re-reads issued past the end must have landed before this workgroup's LDS is handed on; they are older
+    // than the last two chunks' 8 output stores, which need not be waited for (vmcnt counts in issue order)
+    mf_wait_vmcnt<(GWW_MF_ABL & 3) ? 0 : 8>();
+    }
+#else
     // ---- second GEMM: qkv[32 rows, NQ] = LN1(x_next) Wqkv'^T, n-tiles of 128 columns, 6 k-tiles each
     const int T0 = OP_TILES + 6 * nck;
     if (LNQ) {   // first-step fragments of the first tile (the MLP stream's last tile prefetches them otherwise)
@@ -1243,6 +1411,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     // the ring's re-reads issued past the end must have landed before this workgroup's LDS is handed on; they are older
     // than the last n-tile's 8 output stores, which need not be waited for (vmcnt counts in issue order)
     mf_wait_vmcnt<(GWW_MF_ABL & 3) ? 0 : 8>();
+#endif
   }
   MSTAMP(3);
   MSTAMP_FLUSH
@@ -1284,9 +1453,17 @@ __global__ __launch_bounds__(256) void k_mlp_pack(const unsigned short* __restri
       const int nt = tile_all / MF_KT, kt = tile_all - nt * MF_KT;
       v = *reinterpret_cast<const u32x4*>(wo + (long)(128 * nt + row) * MF_D + 64 * kt + 8 * chunk);
     } else if (tile >= mlp_tiles) {
+#if GWW_MF_TAIL2
+      // appended LN1-folded q / k / v panel [NQ, 384] in the fc1 tile format: 64-column chunk cq, three [64 n][128 k] tiles,
+      // 16 chunks per row, chunk ch stored at ch ^ (row & 15)
+      const int it2 = tile - mlp_tiles, cq = it2 / 3, k3 = it2 - 3 * cq;
+      const int row2 = within >> 4, ch = (within & 15) ^ (row2 & 15);
+      v = *reinterpret_cast<const u32x4*>(wq + (long)(64 * cq + row2) * MF_D + 128 * k3 + 8 * ch);
+#else
       // appended LN1-folded q / k / v panel [NQ, 384]: n-tile major, 6 k-tiles each, [128 n][64 k] images
       const int it2 = tile - mlp_tiles, nt = it2 / MF_KT, kt = it2 - nt * MF_KT;
       v = *reinterpret_cast<const u32x4*>(wq + (long)(128 * nt + row) * MF_D + 64 * kt + 8 * chunk);
+#endif
     } else {
       // stream order of k_mlp_fused:  G1(0) | G1(1) G2(0) | G1(2) G2(1) | ... | G1(n-1) G2(n-2) | G2(n-1)
       int kind, cp, idx3;
