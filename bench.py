@@ -607,6 +607,9 @@ def main():
                 # the last block with the final LayerNorm as its epilogue: x 4 B + ctx 2 B in, last_hidden_state 4 B out
                 "mlp_fused+final_layernorm": (B * 4 * T_TOK * d * ffn, M * d * 10),
             }
+            if not traced.get("mel_to_tokens", (0, 0))[1]:
+                # conv1 reads the fp32 [B, 80, T] features itself (conv1_mel.hip): no token-major copy
+                work["conv1_gelu"] = (B * fl["conv1"], B * (80 * T_IN * 4 + (T_IN + 2) * d * es))
             if not traced.get("out_proj", (0, 0))[1] and args.precision == "bf16" and d == 384:
                 # out_proj is fused in front of the MLP block (k_mlp_fused<., true>): its FLOPs and bytes belong to that
                 # launch -- ctx 2 B in instead of the bf16 delta (2 B), nothing else changes at the HBM boundary

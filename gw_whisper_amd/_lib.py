@@ -41,6 +41,11 @@ class DoraTarget(C.Structure):
                 ("dA", C.c_void_p), ("dB", C.c_void_p), ("dm", C.c_void_p)]
 
 
+class DoraMergeItem(C.Structure):
+    _fields_ = [("w0", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("m", C.c_void_p), ("w_eff", C.c_void_p),
+                ("norm_out", C.c_void_p), ("scaling", C.c_float), ("d_out", C.c_int), ("d_in", C.c_int), ("r", C.c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/gww.h declares
 SIGNATURES = {
     "gww_version": (C.c_int, []),
@@ -90,6 +95,9 @@ SIGNATURES = {
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_long, C.c_int, C.c_void_p]),
     "gww_dora_merge_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gww_conv1_gelu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]),
+    "gww_dora_merge_batch_f32": (C.c_int, [C.POINTER(DoraMergeItem), C.c_int, C.c_void_p]),
     "gww_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long,
                                 C.c_int, C.c_void_p]),
     "gww_gemm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
@@ -137,7 +145,7 @@ SIGNATURES = {
     "gww_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
 }
 
-ABI_VERSION = 106   # include/gww.h GWW_VERSION this binding was written against
+ABI_VERSION = 107   # include/gww.h GWW_VERSION this binding was written against
 
 _lib = None
 

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "../../include/gww.h"
+#include <vector>
 
 namespace gww {
 
@@ -133,9 +134,45 @@ int launch_gemm_astat(const void* A, long lda, const void* delta, float* x_out, 
                       const float* ln_cb, const void* W, const float* bias, void* C, long M, int N, int K,
                       int epi, int rows_per_batch, hipStream_t s, long c_panel_rows = 0);
 int launch_cast_f32_bf16(const float* x, void* y, long n, hipStream_t s);
+bool conv1_mel_supported(int n_mels, int d, int kpad);
+int launch_conv1_mel(const float* mel, const void* W, const float* bias, void* c1, int B, int T, int d, hipStream_t s);
 int launch_pack_weight(const float* w, void* out, int out_bf16, int N, int C, int taps, int Kpad,
                        float scale, hipStream_t s);
 int launch_scale_copy(const float* in, float* out, int n, float scale, hipStream_t s);
+
+// Batched weight preparation (elementwise.hip::k_prep_batch): the small row-wise kernels of a weight update collected
+// into one launch per dependency phase.  Ops of ONE batch must not read each other's outputs; flush() between phases.
+enum { PREP_PACK16, PREP_PACK32, PREP_COPY, PREP_LNFOLD, PREP_TRANSPOSE, PREP_DORA };
+constexpr int kPrepMaxOps = 40;      // 40 x 80-byte descriptors + the prefix table stay below the 4-KiB kernel-argument limit
+constexpr int kPrepMaxRank = 1024;   // LoRA rank the DoRA body stages in LDS
+struct PrepOp {
+  const void *a, *b, *c, *d;   // inputs   (kind-specific, see PrepBatch's methods)
+  void *o0, *o1, *o2;          // outputs
+  int kind, blocks, N, K;      // workgroups of the op; rows; columns (Kpad / d_in / Cn)
+  int C, taps;                 // pack: input channels, taps; DoRA: C = rank
+  float scale;
+  int pad_;
+};
+struct PrepArgs {
+  int n;
+  int first[kPrepMaxOps + 1];  // first workgroup of op i; first[n] = grid size
+  PrepOp op[kPrepMaxOps];
+};
+int launch_prep_batch(const PrepArgs& P, hipStream_t s);
+struct PrepBatch {
+  std::vector<PrepArgs> args;  // nothing is launched before flush(): a full table opens the next one
+  hipStream_t s;
+  explicit PrepBatch(hipStream_t st) : s(st) {}
+  int add(const PrepOp& o);
+  int flush();                 // one launch per table, in order
+  int pack(const float* w, void* out, int out_bf16, int N, int C, int taps, int Kpad, float scale);
+  int copy(const float* in, float* out, int n, float scale);
+  int ln_fold(const float* w, const float* g, const float* bl, const float* bias, float scale, int N, int K, void* wp,
+              float* u, float* cb);
+  int transpose(const void* in, void* out, int R, int Cn);
+  int dora(const float* w0, const float* a, const float* b, const float* m, float scaling, int d_out, int d_in, int r,
+           float* w_eff, float* norm_out);
+};
 int launch_gemm_bf16(const void* A, long lda, const void* W, const float* bias, const float* resid,
                      const float* pos, void* C, long M, int N, int K, int epi, int rows_per_batch,
                      hipStream_t s, int rows_padded_256 = 0);

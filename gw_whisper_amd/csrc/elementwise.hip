@@ -127,10 +127,10 @@ int launch_cast_f32_bf16(const float* x, void* y, long n, hipStream_t s) {
 // Pack a [N, C, taps] fp32 weight (taps = 1 for linears, 3 for the convs) into the
 // kernel layout [N, Kpad] with k = tap * C + c, zero for k >= taps*C, scaled.
 template <typename OutT>
-__global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, OutT* __restrict__ out,
-                                                     int N, int C, int taps, int Kpad, float scale) {
+__device__ __forceinline__ void pack_weight_body(const float* __restrict__ w, OutT* __restrict__ out, int N, int C,
+                                                 int taps, int Kpad, float scale, int block, int nblocks) {
   const long total = (long)N * Kpad;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  for (long i = (long)block * 256 + threadIdx.x; i < total; i += (long)nblocks * 256) {
     const int n = (int)(i / Kpad), k = (int)(i - (long)n * Kpad);
     float v = 0.f;
     if (k < taps * C) {
@@ -143,6 +143,12 @@ __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w
       out[i] = v;
     }
   }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, OutT* __restrict__ out,
+                                                     int N, int C, int taps, int Kpad, float scale) {
+  pack_weight_body<OutT>(w, out, N, C, taps, Kpad, scale, (int)blockIdx.x, (int)gridDim.x);
 }
 
 int launch_pack_weight(const float* w, void* out, int out_bf16, int N, int C, int taps, int Kpad,
@@ -176,12 +182,10 @@ int launch_scale_copy(const float* in, float* out, int n, float scale, hipStream
 // For the GEMMs that apply LayerNorm algebraically (gemm_astat.hip): per output row n
 //   W'[n][k] = bf16(scale * g[k] * W[n][k]),  u[n] = sum_k W'[n][k],
 //   cb[n]    = scale * (bias[n] + sum_k b_ln[k] * W[n][k])
-__global__ __launch_bounds__(256) void k_ln_fold(const float* __restrict__ w, const float* __restrict__ g,
-                                                 const float* __restrict__ bl, const float* __restrict__ bias,
-                                                 float scale, int K, unsigned short* __restrict__ wp,
-                                                 float* __restrict__ u, float* __restrict__ cb) {
-  __shared__ float red[8];
-  const int n = blockIdx.x;
+__device__ __forceinline__ void ln_fold_body(const float* __restrict__ w, const float* __restrict__ g,
+                                             const float* __restrict__ bl, const float* __restrict__ bias,
+                                             float scale, int K, unsigned short* __restrict__ wp,
+                                             float* __restrict__ u, float* __restrict__ cb, int n, float* red) {
   float su = 0.f, sc = 0.f;
   for (int k = threadIdx.x; k < K; k += 256) {
     const float wv = w[(long)n * K + k];
@@ -203,6 +207,14 @@ __global__ __launch_bounds__(256) void k_ln_fold(const float* __restrict__ w, co
   }
 }
 
+__global__ __launch_bounds__(256) void k_ln_fold(const float* __restrict__ w, const float* __restrict__ g,
+                                                 const float* __restrict__ bl, const float* __restrict__ bias,
+                                                 float scale, int K, unsigned short* __restrict__ wp,
+                                                 float* __restrict__ u, float* __restrict__ cb) {
+  __shared__ float red[8];
+  ln_fold_body(w, g, bl, bias, scale, K, wp, u, cb, (int)blockIdx.x, red);
+}
+
 int launch_ln_fold(const float* w, const float* g, const float* bl, const float* bias, float scale, int N, int K,
                    void* wp, float* u, float* cb, hipStream_t s) {
   hipLaunchKernelGGL(k_ln_fold, dim3((unsigned)N), dim3(256), 0, s, w, g, bl, bias, scale, K,
@@ -214,14 +226,12 @@ int launch_ln_fold(const float* w, const float* g, const float* bl, const float*
 // ---------------------------------------------------------------- DoRA merge (K11)
 // peft 0.12.0 tuners/lora/dora.py: W' = W0 + s B A ; n = ||W'||_2 per output row ;
 // W_eff = (m / n)[:, None] * W'.  One workgroup per output row; fp32.
-__global__ __launch_bounds__(256) void k_dora_merge(const float* __restrict__ w0, const float* __restrict__ a,
-                                                    const float* __restrict__ b, const float* __restrict__ m,
-                                                    float scaling, int d_in, int r, float* __restrict__ w_eff,
-                                                    float* __restrict__ norm_out) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [r] scaled B row, then [4] partials
-  float* brow = sm;
+__device__ __forceinline__ void dora_merge_body(const float* __restrict__ w0, const float* __restrict__ a,
+                                                const float* __restrict__ b, const float* __restrict__ m,
+                                                float scaling, int d_in, int r, float* __restrict__ w_eff,
+                                                float* __restrict__ norm_out, int row, float* sm) {
+  float* brow = sm;            // [r] scaled B row, then [4] partials
   float* red = sm + r;
-  const int row = blockIdx.x;
   for (int j = threadIdx.x; j < r; j += 256) brow[j] = scaling * b[(long)row * r + j];
   __syncthreads();
   float ss = 0.f;
@@ -240,6 +250,130 @@ __global__ __launch_bounds__(256) void k_dora_merge(const float* __restrict__ w0
   for (int c = threadIdx.x; c < d_in; c += 256) w_eff[(long)row * d_in + c] *= g;   // same thread wrote it
 }
 
+__global__ __launch_bounds__(256) void k_dora_merge(const float* __restrict__ w0, const float* __restrict__ a,
+                                                    const float* __restrict__ b, const float* __restrict__ m,
+                                                    float scaling, int d_in, int r, float* __restrict__ w_eff,
+                                                    float* __restrict__ norm_out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  dora_merge_body(w0, a, b, m, scaling, d_in, r, w_eff, norm_out, (int)blockIdx.x, sm);
+}
+
+// ---------------------------------------------------------------- batched weight preparation
+// A DoRA optimizer step changes 12 (tiny) .. 36 (small) projection weights, and every one of them used to cost a merge, six
+// panel packs, eight bias / gain copies, three LayerNorm folds and a transpose: ~110 launches of 3 - 6 us each per step, a
+// twentieth of the whisper-tiny step.  The same bodies run here as ONE launch per dependency phase: the host collects
+// descriptors (kernel argument, no device table to copy), a workgroup finds its op by a scalar walk over the prefix table.
+__global__ __launch_bounds__(256) void k_prep_batch(const PrepArgs P) {
+  __shared__ __attribute__((aligned(16))) float sm[kPrepMaxRank + 8];
+  __shared__ unsigned short tile[64][66];
+  int id = 0;
+  while (id + 1 < P.n && (int)blockIdx.x >= P.first[id + 1]) ++id;
+  const PrepOp& o = P.op[id];
+  const int lb = (int)blockIdx.x - P.first[id], nb = P.first[id + 1] - P.first[id];
+  switch (o.kind) {
+    case PREP_PACK16:
+      pack_weight_body<unsigned short>((const float*)o.a, (unsigned short*)o.o0, o.N, o.C, o.taps, o.K, o.scale, lb, nb);
+      break;
+    case PREP_PACK32:
+      pack_weight_body<float>((const float*)o.a, (float*)o.o0, o.N, o.C, o.taps, o.K, o.scale, lb, nb);
+      break;
+    case PREP_COPY: {
+      const int i = lb * 256 + threadIdx.x;
+      if (i < o.N) ((float*)o.o0)[i] = o.a ? ((const float*)o.a)[i] * o.scale : 0.f;
+      break;
+    }
+    case PREP_LNFOLD:
+      ln_fold_body((const float*)o.a, (const float*)o.b, (const float*)o.c, (const float*)o.d, o.scale, o.K,
+                   (unsigned short*)o.o0, (float*)o.o1, (float*)o.o2, lb, sm);
+      break;
+    case PREP_TRANSPOSE: {
+      const int nbx = (o.K + 63) / 64;
+      const int r0 = (lb / nbx) * 64, c0 = (lb % nbx) * 64, R = o.N, Cn = o.K;
+      const unsigned short* in = (const unsigned short*)o.a;
+      unsigned short* out = (unsigned short*)o.o0;
+      for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < R && c0 + c < Cn) ? in[(long)(r0 + r) * Cn + c0 + c] : (unsigned short)0;
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (r0 + r < R && c0 + c < Cn) out[(long)(c0 + c) * R + r0 + r] = tile[r][c];
+      }
+      break;
+    }
+    case PREP_DORA:
+      dora_merge_body((const float*)o.a, (const float*)o.b, (const float*)o.c, (const float*)o.d, o.scale, o.K, o.C,
+                      (float*)o.o0, (float*)o.o1, lb, sm);
+      break;
+    default: break;
+  }
+}
+
+int launch_prep_batch(const PrepArgs& P, hipStream_t s) {
+  if (P.n == 0 || P.first[P.n] == 0) return GWW_OK;
+  hipLaunchKernelGGL(k_prep_batch, dim3((unsigned)P.first[P.n]), dim3(256), 0, s, P);
+  GWW_LAUNCH_CHECK();
+  return GWW_OK;
+}
+
+int PrepBatch::add(const PrepOp& o) {
+  if (o.blocks <= 0) return GWW_OK;
+  if (args.empty() || args.back().n == kPrepMaxOps) {
+    args.emplace_back();
+    args.back().n = 0;
+    args.back().first[0] = 0;
+  }
+  PrepArgs& t = args.back();
+  t.op[t.n] = o;
+  t.first[t.n + 1] = t.first[t.n] + o.blocks;
+  ++t.n;
+  return GWW_OK;
+}
+
+int PrepBatch::flush() {
+  for (const PrepArgs& t : args) GWW_TRY(launch_prep_batch(t, s));
+  args.clear();
+  return GWW_OK;
+}
+
+int PrepBatch::pack(const float* w, void* out, int out_bf16, int N, int C, int taps, int Kpad, float scale) {
+  PrepOp o{};
+  o.kind = out_bf16 ? PREP_PACK16 : PREP_PACK32;
+  o.a = w; o.o0 = out; o.N = N; o.C = C; o.taps = taps; o.K = Kpad; o.scale = scale;
+  long b = cdiv((long)N * Kpad, 256);
+  o.blocks = (int)(b > 1024 ? 1024 : b);
+  return add(o);
+}
+
+int PrepBatch::copy(const float* in, float* out, int n, float scale) {
+  PrepOp o{};
+  o.kind = PREP_COPY; o.a = in; o.o0 = out; o.N = n; o.scale = scale; o.blocks = (int)cdiv(n, 256);
+  return add(o);
+}
+
+int PrepBatch::ln_fold(const float* w, const float* g, const float* bl, const float* bias, float scale, int N, int K,
+                       void* wp, float* u, float* cb) {
+  PrepOp o{};
+  o.kind = PREP_LNFOLD; o.a = w; o.b = g; o.c = bl; o.d = bias; o.scale = scale; o.N = N; o.K = K;
+  o.o0 = wp; o.o1 = u; o.o2 = cb; o.blocks = N;
+  return add(o);
+}
+
+int PrepBatch::transpose(const void* in, void* out, int R, int Cn) {
+  PrepOp o{};
+  o.kind = PREP_TRANSPOSE; o.a = in; o.o0 = out; o.N = R; o.K = Cn; o.blocks = (int)(cdiv(R, 64) * cdiv(Cn, 64));
+  return add(o);
+}
+
+int PrepBatch::dora(const float* w0, const float* a, const float* b, const float* m, float scaling, int d_out, int d_in,
+                    int r, float* w_eff, float* norm_out) {
+  PrepOp o{};
+  o.kind = PREP_DORA; o.a = w0; o.b = a; o.c = b; o.d = m; o.scale = scaling; o.N = d_out; o.K = d_in; o.C = r;
+  o.o0 = w_eff; o.o1 = norm_out; o.blocks = d_out;
+  return add(o);
+}
+
 }  // namespace gww
 
 using namespace gww;
@@ -253,6 +387,20 @@ extern "C" int gww_dora_merge_f32(const float* w0, const float* a, const float* 
                      (hipStream_t)stream, w0, a, b, m, scaling, d_in, r, w_eff, norm_out);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
+}
+
+extern "C" int gww_dora_merge_batch_f32(const gww_dora_merge_item* items, int n, void* stream) {
+  GWW_REQUIRE(items || n == 0, "gww_dora_merge_batch_f32: NULL items");
+  GWW_REQUIRE(n >= 0, "gww_dora_merge_batch_f32: n < 0");
+  PrepBatch pb((hipStream_t)stream);
+  for (int i = 0; i < n; ++i) {
+    const gww_dora_merge_item& t = items[i];
+    GWW_REQUIRE(t.w0 && t.a && t.b && t.m && t.w_eff, "gww_dora_merge_batch_f32: NULL pointer in item %d", i);
+    GWW_REQUIRE(t.d_out > 0 && t.d_in > 0 && t.r > 0 && t.r <= kPrepMaxRank,
+                "gww_dora_merge_batch_f32: bad shape %dx%d r=%d in item %d", t.d_out, t.d_in, t.r, i);
+    GWW_TRY(pb.dora(t.w0, t.a, t.b, t.m, t.scaling, t.d_out, t.d_in, t.r, t.w_eff, t.norm_out));
+  }
+  return pb.flush();
 }
 
 extern "C" int gww_ln_fold_weights(const float* w, const float* ln_w, const float* ln_b, const float* bias, float scale,

@@ -279,10 +279,14 @@ static int pack_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_
                         const unsigned* dirty, hipStream_t s) {
   const int d = e->cfg.d_model, F = e->cfg.ffn, C = e->cfg.n_mels, T = e->cfg.t_in / 2;
   const float qs = 0.125f;   // head_dim^-0.5 = 64^-0.5, exact power of two (HF:modeling_whisper.py:309)
+  // Two dependency phases, one k_prep_batch launch each (per 40 ops): `pb` reads only the caller's fp32 tensors, `pt` (the
+  // transposes for the backward's dX GEMMs) reads panels `pb` wrote.  A DoRA step on whisper-tiny used to enqueue ~75 launches
+  // of 3 - 6 us here.
+  PrepBatch pb(s), pt(s);
   auto pack = [&](const float* w, unsigned short* o16, float* o32, int N, int Cin, int taps, int Kpad,
                   float scale) -> int {
-    GWW_TRY(launch_pack_weight(w, o16, 1, N, Cin, taps, Kpad, scale, s));
-    GWW_TRY(launch_pack_weight(w, o32, 0, N, Cin, taps, Kpad, scale, s));
+    GWW_TRY(pb.pack(w, o16, 1, N, Cin, taps, Kpad, scale));
+    GWW_TRY(pb.pack(w, o32, 0, N, Cin, taps, Kpad, scale));
     return GWW_OK;
   };
   if (g) {
@@ -291,13 +295,13 @@ static int pack_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_
     GWW_TRY(pack(g->conv1_w, e->c1w, e->c1w32, d, C, 3, kConv1Kpad, 1.f));
     GWW_TRY(pack(g->conv2_w, e->c2w, e->c2w32, d, d, 3, 3 * d, 1.f));
     if (d % 256 != 0) GWW_HIP(hipMemsetAsync(e->c2w + (size_t)d * 3 * d, 0, (size_t)((d + 255) / 256 * 256 - d) * 3 * d * 2, s));
-    GWW_TRY(launch_transpose_bf16(e->c1w, e->c1wT, d, kConv1Kpad, s));
-    GWW_TRY(launch_transpose_bf16(e->c2w, e->c2wT, d, 3 * d, s));
-    GWW_TRY(launch_scale_copy(g->conv1_b, e->c1b, d, 1.f, s));
-    GWW_TRY(launch_scale_copy(g->conv2_b, e->c2b, d, 1.f, s));
+    GWW_TRY(pt.transpose(e->c1w, e->c1wT, d, kConv1Kpad));
+    GWW_TRY(pt.transpose(e->c2w, e->c2wT, d, 3 * d));
+    GWW_TRY(pb.copy(g->conv1_b, e->c1b, d, 1.f));
+    GWW_TRY(pb.copy(g->conv2_b, e->c2b, d, 1.f));
     GWW_HIP(hipMemcpyAsync(e->pos, g->pos, (size_t)T * d * 4, hipMemcpyDeviceToDevice, s));
-    GWW_TRY(launch_scale_copy(g->ln_w, e->lnw, d, 1.f, s));
-    GWW_TRY(launch_scale_copy(g->ln_b, e->lnb, d, 1.f, s));
+    GWW_TRY(pb.copy(g->ln_w, e->lnw, d, 1.f));
+    GWW_TRY(pb.copy(g->ln_b, e->lnb, d, 1.f));
   }
   for (int i = 0; i < n_layers; ++i) {
     const unsigned m = dirty ? dirty[i] : 15u;
@@ -312,49 +316,51 @@ static int pack_weights(gww_encoder* e, const gww_enc_globals* g, const gww_enc_
       // attention_bwd.hip and the DoRA-gradient scale of q follow suit): log2(e) / 8 instead of 1 / 8.  The fp32 parity
       // panels keep natural units.
       const float qs16 = attention_log2q_enabled() ? qs * 1.44269504088896340736f : qs;
-      GWW_TRY(launch_pack_weight(L.q_w, w.wqkv, 1, d, d, 1, d, qs16, s));
-      GWW_TRY(launch_pack_weight(L.q_w, w.wqkv32, 0, d, d, 1, d, qs, s));
+      GWW_TRY(pb.pack(L.q_w, w.wqkv, 1, d, d, 1, d, qs16));
+      GWW_TRY(pb.pack(L.q_w, w.wqkv32, 0, d, d, 1, d, qs));
       GWW_TRY(pack(L.k_w, w.wqkv + dd, w.wqkv32 + dd, d, d, 1, d, 1.f));
       GWW_TRY(pack(L.v_w, w.wqkv + 2 * dd, w.wqkv32 + 2 * dd, d, d, 1, d, 1.f));
-      GWW_TRY(launch_scale_copy(L.q_b, w.bqkv, d, qs, s));
-      GWW_TRY(launch_scale_copy(nullptr, w.bqkv + d, d, 0.f, s));   // k_proj has no bias
-      GWW_TRY(launch_scale_copy(L.v_b, w.bqkv + 2 * d, d, 1.f, s));
-      GWW_TRY(launch_scale_copy(L.q_b, w.bqkv16, d, qs16, s));
-      GWW_TRY(launch_scale_copy(nullptr, w.bqkv16 + d, d, 0.f, s));
-      GWW_TRY(launch_scale_copy(L.v_b, w.bqkv16 + 2 * d, d, 1.f, s));
-      GWW_TRY(launch_scale_copy(L.ln1_w, w.ln1w, d, 1.f, s));
-      GWW_TRY(launch_scale_copy(L.ln1_b, w.ln1b, d, 1.f, s));
+      GWW_TRY(pb.copy(L.q_b, w.bqkv, d, qs));
+      GWW_TRY(pb.copy(nullptr, w.bqkv + d, d, 0.f));   // k_proj has no bias
+      GWW_TRY(pb.copy(L.v_b, w.bqkv + 2 * d, d, 1.f));
+      GWW_TRY(pb.copy(L.q_b, w.bqkv16, d, qs16));
+      GWW_TRY(pb.copy(nullptr, w.bqkv16 + d, d, 0.f));
+      GWW_TRY(pb.copy(L.v_b, w.bqkv16 + 2 * d, d, 1.f));
+      GWW_TRY(pb.copy(L.ln1_w, w.ln1w, d, 1.f));
+      GWW_TRY(pb.copy(L.ln1_b, w.ln1b, d, 1.f));
       // gain-folded panel + correction vectors for the algebraic LayerNorm of the A-stationary GEMM
       // (the A-stationary inference path feeds k_attention_l2_bf16, which takes q in log2 units: log2(e) rides in
       // the q panel, one rounding of the fp32 product instead of a second one on bf16 q)
-      GWW_TRY(launch_ln_fold(L.q_w, L.ln1_w, L.ln1_b, L.q_b, qs16, d, d, w.wqkv_ln, w.uqkv, w.cbqkv, s));
-      GWW_TRY(launch_ln_fold(L.k_w, L.ln1_w, L.ln1_b, nullptr, 1.f, d, d, w.wqkv_ln + dd, w.uqkv + d, w.cbqkv + d, s));
-      GWW_TRY(launch_ln_fold(L.v_w, L.ln1_w, L.ln1_b, L.v_b, 1.f, d, d, w.wqkv_ln + 2 * dd, w.uqkv + 2 * d,
-                             w.cbqkv + 2 * d, s));
-      GWW_TRY(launch_transpose_bf16(w.wqkv, w.wqkvT, 3 * d, d, s));   // [N][K] -> [K][N] for the backward dX GEMM
+      GWW_TRY(pb.ln_fold(L.q_w, L.ln1_w, L.ln1_b, L.q_b, qs16, d, d, w.wqkv_ln, w.uqkv, w.cbqkv));
+      GWW_TRY(pb.ln_fold(L.k_w, L.ln1_w, L.ln1_b, nullptr, 1.f, d, d, w.wqkv_ln + dd, w.uqkv + d, w.cbqkv + d));
+      GWW_TRY(pb.ln_fold(L.v_w, L.ln1_w, L.ln1_b, L.v_b, 1.f, d, d, w.wqkv_ln + 2 * dd, w.uqkv + 2 * d,
+                             w.cbqkv + 2 * d));
+      GWW_TRY(pt.transpose(w.wqkv, w.wqkvT, 3 * d, d));   // [N][K] -> [K][N] for the backward dX GEMM
     }
     if (m & 2u) {
       GWW_REQUIRE(L.o_w && L.o_b, "gww_encoder_set_weights: NULL out_proj weight in layer %d", i);
       GWW_TRY(pack(L.o_w, w.wo, w.wo32, d, d, 1, d, 1.f));
-      GWW_TRY(launch_scale_copy(L.o_b, w.bo, d, 1.f, s));
-      GWW_TRY(launch_transpose_bf16(w.wo, w.woT, d, d, s));
+      GWW_TRY(pb.copy(L.o_b, w.bo, d, 1.f));
+      GWW_TRY(pt.transpose(w.wo, w.woT, d, d));
     }
     if (m & 4u) {
       GWW_REQUIRE(L.ln2_w && L.ln2_b && L.fc1_w && L.fc1_b, "gww_encoder_set_weights: NULL fc1 weight in layer %d", i);
       GWW_TRY(pack(L.fc1_w, w.w1, w.w132, F, d, 1, d, 1.f));
-      GWW_TRY(launch_scale_copy(L.fc1_b, w.b1, F, 1.f, s));
-      GWW_TRY(launch_scale_copy(L.ln2_w, w.ln2w, d, 1.f, s));
-      GWW_TRY(launch_scale_copy(L.ln2_b, w.ln2b, d, 1.f, s));
-      GWW_TRY(launch_ln_fold(L.fc1_w, L.ln2_w, L.ln2_b, L.fc1_b, 1.f, F, d, w.w1_ln, w.u1, w.cb1, s));
-      GWW_TRY(launch_transpose_bf16(w.w1, w.w1T, F, d, s));
+      GWW_TRY(pb.copy(L.fc1_b, w.b1, F, 1.f));
+      GWW_TRY(pb.copy(L.ln2_w, w.ln2w, d, 1.f));
+      GWW_TRY(pb.copy(L.ln2_b, w.ln2b, d, 1.f));
+      GWW_TRY(pb.ln_fold(L.fc1_w, L.ln2_w, L.ln2_b, L.fc1_b, 1.f, F, d, w.w1_ln, w.u1, w.cb1));
+      GWW_TRY(pt.transpose(w.w1, w.w1T, F, d));
     }
     if (m & 8u) {
       GWW_REQUIRE(L.fc2_w && L.fc2_b, "gww_encoder_set_weights: NULL fc2 weight in layer %d", i);
       GWW_TRY(pack(L.fc2_w, w.w2, w.w232, d, F, 1, F, 1.f));
-      GWW_TRY(launch_scale_copy(L.fc2_b, w.b2, d, 1.f, s));
-      GWW_TRY(launch_transpose_bf16(w.w2, w.w2T, d, F, s));
+      GWW_TRY(pb.copy(L.fc2_b, w.b2, d, 1.f));
+      GWW_TRY(pt.transpose(w.w2, w.w2T, d, F));
     }
   }
+  GWW_TRY(pb.flush());
+  GWW_TRY(pt.flush());
   // the fused-MLP weight stream of layer i: folded fc1 panel, fc2 and the folded q / k / v panel of layer i + 1
   if (d == 384 && F % 128 == 0 && F <= 1536) {
     for (int i = 0; i < n_layers; ++i) {
@@ -516,13 +522,18 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   };
 
   // ---- stem
-  TR(TR_MEL, launch_mel_to_tokens(mel, melT, bf ? 1 : 0, B, C, Tin, s));
-  GWW_HIP(hipMemsetAsync((char*)melT + (size_t)B * (Tin + 2) * C * es, 0, kConv1Kpad * es, s));
-  GWW_HIP(hipMemsetAsync(c1, 0, (size_t)d * es, s));   // zero row 0 of batch 0 (token -1)
+  // bf16, the widths of whisper-tiny / -base / -small / -medium: conv1 reads the [B, 80, T] features itself (conv1_mel.hip:
+  // no token-major copy of the input, W-stationary, one launch); otherwise the transposition kernel + a GEMM over its rows
+  static const int generic_mask = (int)lab_int("GWW_GENERIC_PATH", 0);   // (0 in the product build)
+  const bool conv1_direct = bf && conv1_mel_supported(C, d, kConv1Kpad) && !(generic_mask & 2);
+  if (!conv1_direct) {
+    TR(TR_MEL, launch_mel_to_tokens(mel, melT, bf ? 1 : 0, B, C, Tin, s));
+    GWW_HIP(hipMemsetAsync((char*)melT + (size_t)B * (Tin + 2) * C * es, 0, kConv1Kpad * es, s));
+    GWW_HIP(hipMemsetAsync(c1, 0, (size_t)d * es, s));   // zero row 0 of batch 0 (token -1)
+  }
   // A-stationary kernels (A panel in registers, fused residual-add + LayerNorm prologue) for K = d <= 512
   // GWW_GENERIC_PATH (debug aid): bit 0 = generic layer GEMMs, bit 1 = generic conv1, bit 2 = generic conv2, bit 3 = unfused MLP,
   // bit 4 = stand-alone QKV, bit 5 = no pooled last layer, bit 6 = layer 0's LN1 + QKV by the LN-fused A-stationary GEMM, bit 7 = stand-alone out_proj, bit 8 = stand-alone final LayerNorm, bit 9 = A-stationary layer GEMMs at d = 512
-  static const int generic_mask = (int)lab_int("GWW_GENERIC_PATH", 0);   // (0 in the product build)
   // d = 512 (whisper-base): since round 3 the LayerNorm kernel + the 256 x 256 GEMM (k_gemm_bf16_v3) beat the LN-fused
   // A-stationary layer GEMMs there (8.78 against 9.33 ms per 64 segments; bit 9 of the mask brings them back)
   const bool astat = bf && (d == 384 || (d == 512 && (generic_mask & 512))) && F % 128 == 0 && !(generic_mask & 1);
@@ -531,7 +542,9 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
   bool qkv_done = false;
   // only the last token wanted: the last layer runs on B rows above its attention (bit 5 of the mask disables it)
   const bool pooled = astat && !last_hidden && last_token && T >= 3 && !(generic_mask & 32);
-  if (bf && d % 128 == 0 && !(generic_mask & 2))
+  if (conv1_direct)
+    TR(TR_CONV1, launch_conv1_mel(mel, e->c1w, e->c1b, c1, B, Tin, d, s));
+  else if (bf && d % 128 == 0 && !(generic_mask & 2))
     TR(TR_CONV1, launch_gemm_astat(melT, C, nullptr, nullptr, nullptr, nullptr, e->c1w, e->c1b, c1,
                                    (long)B * (Tin + 2), d, kConv1Kpad, EPI_CONV1, Tin + 2, s));
   else

@@ -185,6 +185,18 @@ class WhisperEncoder(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
+        # every DoRA-wrapped projection of a dirty group merged by one launch
+        wrapped = []
+        for L, m in zip(self.layers, masks):
+            a = L.self_attn
+            for bit, mods in ((1, (a.q_proj, a.k_proj, a.v_proj)), (2, (a.out_proj,)), (4, (L.fc1,)), (8, (L.fc2,))):
+                if m & bit:
+                    wrapped += [x for x in mods if hasattr(x, "effective_weights")]
+        merged = {}
+        if wrapped:
+            merged = {id(x): w for x, w in zip(wrapped, type(wrapped[0]).effective_weights(wrapped))}
+        eff = lambda lin: merged[id(lin)] if id(lin) in merged else _effective_weight(lin)
+
         g = None
         if g_dirty:
             g = _lib.EncGlobals(ptr(self.conv1.weight), ptr(self.conv1.bias), ptr(self.conv2.weight),
@@ -197,13 +209,13 @@ class WhisperEncoder(nn.Module):
             z = lambda cond, fn: fn() if cond else None       # clean groups: pointers are not read
             arr[i] = _lib.EncLayer(
                 z(m & 1, lambda: ptr(L.self_attn_layer_norm.weight)), z(m & 1, lambda: ptr(L.self_attn_layer_norm.bias)),
-                z(m & 1, lambda: ptr(_effective_weight(a.q_proj))), z(m & 1, lambda: ptr(_bias(a.q_proj))),
-                z(m & 1, lambda: ptr(_effective_weight(a.k_proj))),
-                z(m & 1, lambda: ptr(_effective_weight(a.v_proj))), z(m & 1, lambda: ptr(_bias(a.v_proj))),
-                z(m & 2, lambda: ptr(_effective_weight(a.out_proj))), z(m & 2, lambda: ptr(_bias(a.out_proj))),
+                z(m & 1, lambda: ptr(eff(a.q_proj))), z(m & 1, lambda: ptr(_bias(a.q_proj))),
+                z(m & 1, lambda: ptr(eff(a.k_proj))),
+                z(m & 1, lambda: ptr(eff(a.v_proj))), z(m & 1, lambda: ptr(_bias(a.v_proj))),
+                z(m & 2, lambda: ptr(eff(a.out_proj))), z(m & 2, lambda: ptr(_bias(a.out_proj))),
                 z(m & 4, lambda: ptr(L.final_layer_norm.weight)), z(m & 4, lambda: ptr(L.final_layer_norm.bias)),
-                z(m & 4, lambda: ptr(_effective_weight(L.fc1))), z(m & 4, lambda: ptr(_bias(L.fc1))),
-                z(m & 8, lambda: ptr(_effective_weight(L.fc2))), z(m & 8, lambda: ptr(_bias(L.fc2))))
+                z(m & 4, lambda: ptr(eff(L.fc1))), z(m & 4, lambda: ptr(_bias(L.fc1))),
+                z(m & 8, lambda: ptr(eff(L.fc2))), z(m & 8, lambda: ptr(_bias(L.fc2))))
         stream = torch.cuda.current_stream().cuda_stream
         if full:
             check(lib().gww_encoder_set_weights(self._ensure_handle(), C.byref(g), arr, n, stream),

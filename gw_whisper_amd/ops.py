@@ -378,6 +378,49 @@ def dora_merge(w0: torch.Tensor, a: torch.Tensor, b: torch.Tensor, m: torch.Tens
     return (out, nrm) if return_norm else out
 
 
+def conv1_gelu(mel: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """``gelu(conv1(input_features))`` of the Whisper stem (HF:modeling_whisper.py:619-620) read straight from the
+    ``[B, 80, T]`` feature layout -> token-major bf16 ``[B, T + 2, d]`` with zero rows 0 and T + 1 (conv2's padding)."""
+    mel = _dev(mel, torch.float32, "mel")
+    weight, bias = _dev(weight, torch.float32, "weight"), _dev(bias, torch.float32, "bias")
+    B, C_, T = mel.shape
+    d = weight.shape[0]
+    if C_ != 80 or tuple(weight.shape) != (d, 80, 3) or tuple(bias.shape) != (d,):
+        raise _lib.GwwError(f"conv1_gelu: mel {tuple(mel.shape)}, weight {tuple(weight.shape)}, bias {tuple(bias.shape)}")
+    scratch = torch.empty((d, 256), dtype=torch.bfloat16, device=mel.device)
+    out = torch.empty((B, T + 2, d), dtype=torch.bfloat16, device=mel.device)
+    with torch.cuda.device(mel.device):
+        check(lib().gww_conv1_gelu_bf16(mel.data_ptr(), weight.data_ptr(), bias.data_ptr(), scratch.data_ptr(), out.data_ptr(),
+                                        B, T, d, _stream()), "gww_conv1_gelu_bf16")
+    return out
+
+
+def dora_merge_batch(items, return_norm: bool = True):
+    """``dora_merge`` for a list of ``(w0, a, b, m, scaling)`` tuples in ONE launch (an optimizer step changes every
+    adapted projection at once; a launch per 384 x 384 matrix is launch-bound).  Returns a list of ``(w_eff, norm)``."""
+    if not items:
+        return []
+    dev = items[0][0].device
+    arr = (_lib.DoraMergeItem * len(items))()
+    out, keep = [], []
+    for i, (w0, a, b, m, scaling) in enumerate(items):
+        w0, a, b, m = (_dev(t, torch.float32) for t in (w0, a, b, m))
+        d_out, d_in = w0.shape
+        r = a.shape[0]
+        if a.shape != (r, d_in) or b.shape != (d_out, r) or m.shape != (d_out,) or w0.device != dev:
+            raise _lib.GwwError(f"dora_merge_batch: item {i}: shapes {tuple(w0.shape)} {tuple(a.shape)} {tuple(b.shape)} "
+                                f"{tuple(m.shape)} or device do not fit")
+        w = torch.empty_like(w0)
+        nrm = torch.empty((d_out,), dtype=torch.float32, device=dev)
+        keep += [w0, a, b, m]
+        arr[i] = _lib.DoraMergeItem(w0.data_ptr(), a.data_ptr(), b.data_ptr(), m.data_ptr(), w.data_ptr(), nrm.data_ptr(),
+                                    float(scaling), d_out, d_in, r)
+        out.append((w, nrm))
+    with torch.cuda.device(dev):
+        check(lib().gww_dora_merge_batch_f32(arr, len(items), _stream()), "gww_dora_merge_batch_f32")
+    return out if return_norm else [w for w, _ in out]
+
+
 # ------------------------------------------------------------------ training-step kernels
 def attention_lse(qkv: torch.Tensor, n_heads: int):
     """bf16 attention forward that also returns the row log-sum-exp [B, H, T] (fp32)."""

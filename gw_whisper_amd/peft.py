@@ -119,21 +119,35 @@ class DoraLinear(nn.Module):
     def bias(self):
         return self.base_layer.bias
 
-    def effective_weight(self) -> torch.Tensor:
-        """Dense fp32 weight this layer represents right now (HIP merge kernel on the GPU)."""
-        from . import ops
+    def _merge_operands(self):
         W0 = self.base_layer.weight.detach()
         A = self.lora_A[self.adapter].weight.detach()
         B = self.lora_B[self.adapter].weight.detach()
         if self.use_dora:
             m = self.lora_magnitude_vector[self.adapter].weight.detach()
-            merged, self._last_norm = ops.dora_merge(W0.float(), A.float(), B.float(), m.float(), self.scaling,
-                                                     return_norm=True)     # ||W'|| rows: the backward's detached norm
+        else:   # plain LoRA: the same kernel with m := 1, the row norm multiplied back in afterwards
+            m = torch.ones(self.out_features, device=W0.device)
+        return W0.float(), A.float(), B.float(), m.float(), self.scaling
+
+    def _merged(self, merged, nrm):
+        if self.use_dora:
+            self._last_norm = nrm     # ||W'|| rows: the backward's detached norm
             return merged
-        # plain LoRA: same kernel with m := ||W'|| would be a no-op scale; merge = W0 + s B A
-        ones = torch.ones(self.out_features, device=W0.device)
-        merged, nrm = ops.dora_merge(W0.float(), A.float(), B.float(), ones, self.scaling, return_norm=True)
-        return merged * nrm[:, None]
+        return merged * nrm[:, None]  # merge = W0 + s B A
+
+    def effective_weight(self) -> torch.Tensor:
+        """Dense fp32 weight this layer represents right now (HIP merge kernel on the GPU)."""
+        from . import ops
+        merged, nrm = ops.dora_merge(*self._merge_operands(), return_norm=True)
+        return self._merged(merged, nrm)
+
+    @staticmethod
+    def effective_weights(mods) -> list:
+        """``effective_weight()`` of several wrappers through ONE launch (``gww_dora_merge_batch_f32``): what the encoder
+        calls after an optimizer step, which changes every adapted projection at once."""
+        from . import ops
+        outs = ops.dora_merge_batch([m._merge_operands() for m in mods])
+        return [m._merged(w, n) for m, (w, n) in zip(mods, outs)]
 
 
 def _match(name: str, targets) -> bool:

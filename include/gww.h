@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GWW_VERSION 106  /* 0.1.6: + gww_qadapter_cnn_backward_f32 / _workspace_bytes (the Q-adapter CNN's backward as HIP kernels); 0.1.5: + gww_gemm_bf16_v4_split (explicit column split; no environment switch is read by the library any more); 0.1.4: gww_mlp_fused_bf16 / gww_attn_out_mlp_fused_bf16 with the q / k / v tail return x_next over x (x_out keeps x_new); 0.1.3: + gww_logmel_host_f32 (fork-safe CPU twin of the front end); 0.1.2: + whitening kernels, gww_qadapter_tail_f32, gww_attention_bwd_log2q_bf16, gww_lnqkv_fused_bf16, gww_attn_out_mlp_fused_bf16, gww_mlp_pack_op_bf16; the gww_mlp_pack_bf16 stream carries W1 / 8 and 8 W2 */
+#define GWW_VERSION 107  /* 0.1.7: + gww_dora_merge_batch_f32 (all adapted projections of a step in one launch), gww_conv1_gelu_bf16 (conv1 read from the [B, 80, T] feature layout); 0.1.6: + gww_qadapter_cnn_backward_f32 / _workspace_bytes (the Q-adapter CNN's backward as HIP kernels); 0.1.5: + gww_gemm_bf16_v4_split (explicit column split; no environment switch is read by the library any more); 0.1.4: gww_mlp_fused_bf16 / gww_attn_out_mlp_fused_bf16 with the q / k / v tail return x_next over x (x_out keeps x_new); 0.1.3: + gww_logmel_host_f32 (fork-safe CPU twin of the front end); 0.1.2: + whitening kernels, gww_qadapter_tail_f32, gww_attention_bwd_log2q_bf16, gww_lnqkv_fused_bf16, gww_attn_out_mlp_fused_bf16, gww_mlp_pack_op_bf16; the gww_mlp_pack_bf16 stream carries W1 / 8 and 8 W2 */
 
 #define GWW_OK 0
 #define GWW_ERR_ARG (-1)      /* bad argument (shape, null pointer, unsupported size) */
@@ -152,6 +152,32 @@ const char* gww_encoder_trace_class_name(int i);
 int gww_dora_merge_f32(const float* w0, const float* a, const float* b, const float* m,
                        float scaling, int d_out, int d_in, int r,
                        float* w_eff, float* norm_out, void* stream);
+
+/* --------------------------------------------------------------------------
+ * conv1 of the stem straight from the HF feature layout (bf16 path, kernel-level entry; the encoder calls the same
+ * kernel).  Replaces  nn.functional.gelu(self.conv1(input_features))  of HF:models/whisper/modeling_whisper.py:619-620
+ * (reached from Signal_vs_Noise/src/model.py:25, Glitch_classification/src/model.py, MLGWSC-1/inference.py:353-392).
+ *   mel [B, 80, T] fp32, conv1_w [d, 80, 3] fp32, conv1_b [d] fp32; w_scratch_bf16: d * 256 bf16 of scratch (packed
+ *   taps); c1_out [B, T + 2, d] bf16 token-major, rows 0 and T + 1 of every segment zero (the padding conv2 reads).
+ *   d in {384, 512, 768, 1024}.
+ * -------------------------------------------------------------------------- */
+int gww_conv1_gelu_bf16(const float* mel, const float* conv1_w, const float* conv1_b, void* w_scratch_bf16,
+                        void* c1_out, int B, int T, int d, void* stream);
+
+/* The same merge for every adapted projection of a model in ONE launch: an optimizer step changes all of them at once
+ * (12 modules on whisper-tiny, 36 on whisper-small: Signal_vs_Noise/src/train.py:263-264 targets q, k, v of every
+ * layer), and a launch per 384 x 384 matrix is launch-bound.  Items are independent; pointers as above. */
+typedef struct {
+  const float* w0;      /* [d_out, d_in] frozen base weight */
+  const float* a;       /* [r, d_in]     lora_A.weight */
+  const float* b;       /* [d_out, r]    lora_B.weight */
+  const float* m;       /* [d_out]       lora_magnitude_vector (ones for plain LoRA) */
+  float* w_eff;         /* [d_out, d_in] out */
+  float* norm_out;      /* [d_out] out, may be NULL */
+  float scaling;        /* lora_alpha / r */
+  int d_out, d_in, r;
+} gww_dora_merge_item;
+int gww_dora_merge_batch_f32(const gww_dora_merge_item* items, int n, void* stream);
 
 /* --------------------------------------------------------------------------
  * DoRA training step (bf16).  Replaces loss.backward() through the frozen encoder with DoRA

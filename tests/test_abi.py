@@ -21,7 +21,7 @@ def _header_symbols():
 def test_library_present_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
     lib = gw_whisper_amd.lib()
-    assert lib.gww_version() == 106
+    assert lib.gww_version() == 107
 
 
 def test_every_header_symbol_is_exported_and_bound():

@@ -448,6 +448,50 @@ def test_dora_merge(T, gww, d_out, d_in, r):
     np.testing.assert_allclose(got0.cpu().numpy(), W0, atol=1e-6, rtol=1e-6)
 
 
+@pytest.mark.parametrize("B,Tn,d", [(2, 3000, 384), (3, 100, 384), (2, 257, 384), (1, 128, 512), (2, 129, 768), (1, 1, 1024),
+                                    (300, 40, 384)])
+def test_conv1_gelu_from_the_feature_layout(T, gww, B, Tn, d):
+    """gww_conv1_gelu_bf16 (conv1_mel.hip: conv1 + GELU read straight from [B, 80, T], HF:modeling_whisper.py:619-620)
+    against torch's fp64 Conv1d + erf GELU on the same bf16-rounded operands; ragged chunk tails (T % 128 != 0), a single
+    sample, more chunks than workgroups; the padding rows 0 and T + 1 of every segment must be exact zeros."""
+    from gw_whisper_amd import ops
+    rng = np.random.default_rng(B * 7 + Tn + d)
+    mel = T.from_numpy(rng.standard_normal((B, 80, Tn)).astype(np.float32) * 0.8)
+    w = T.from_numpy((rng.standard_normal((d, 80, 3)) / np.sqrt(240)).astype(np.float32))
+    b = T.from_numpy(rng.standard_normal(d).astype(np.float32) * 0.3)
+    got = ops.conv1_gelu(mel.cuda(), w.cuda(), b.cuda())
+    assert got.shape == (B, Tn + 2, d) and got.dtype == T.bfloat16
+    got = got.float().cpu()
+    assert T.count_nonzero(got[:, 0]) == 0 and T.count_nonzero(got[:, Tn + 1]) == 0
+    r16 = lambda t: t.to(T.bfloat16).to(T.float64)
+    ref = T.nn.functional.gelu(T.nn.functional.conv1d(r16(mel), r16(w), b.double(), padding=1)).transpose(1, 2)
+    err = (got[:, 1:Tn + 1].double() - ref).abs()
+    assert float((err - (2.0 ** -8) * ref.abs()).max()) < 1e-3, float(err.max())
+
+
+def test_dora_merge_batch_equals_the_single_merges(T, gww):
+    """gww_dora_merge_batch_f32: 45 modules of mixed shape and rank (more than one 40-op descriptor table) in one call,
+    bit-identical to the per-module kernel and within the oracle's tolerance."""
+    from gw_whisper_amd import ops
+    shapes = [(384, 384, 8), (768, 768, 16), (1536, 384, 8), (384, 1536, 4), (512, 512, 32)] * 9
+    items, refs = [], []
+    for i, (d_out, d_in, r) in enumerate(shapes):
+        rng = np.random.default_rng(100 + i)
+        W0 = (rng.standard_normal((d_out, d_in)) / np.sqrt(d_in)).astype(np.float32)
+        A, B, m = synth.dora_adapter(d_out, d_in, r, W0, seed=i)
+        items.append(tuple(T.from_numpy(t).cuda() for t in (W0, A, B, m)) + (32.0 / r,))
+        if i < 5:
+            refs.append(odora.dora_merge(*(t.astype(np.float64) for t in (W0, A, B, m)), 32.0 / r))
+    got = ops.dora_merge_batch(items)
+    assert len(got) == len(items)
+    for i, (it, (w, nrm)) in enumerate(zip(items, got)):
+        w1, n1 = ops.dora_merge(*it[:4], it[4], return_norm=True)
+        assert T.equal(w, w1) and T.equal(nrm, n1), i
+    for ref, (w, _) in zip(refs, got):
+        np.testing.assert_allclose(w.cpu().numpy(), ref, atol=2e-6, rtol=1e-5)
+    assert ops.dora_merge_batch([]) == []
+
+
 def test_mlp_pack_layout(T, gww):
     """Tile stream of the fused MLP, in the order the kernel consumes it over 64-column ffn chunks c':
     G1(0) | G1(1) G2(0) | G1(2) G2(1) | ... | G1(n-1) G2(n-2) | G2(n-1); fc1 tiles are swizzled [64 n][128 k] images,
