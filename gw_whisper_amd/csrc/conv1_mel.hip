@@ -133,7 +133,8 @@ __global__ __launch_bounds__(512, 1) void k_conv1_mel(const float* __restrict__ 
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
           const f32x4 v = acc[cb] + bv[cb];
-          const u32x2 o = {pack2bf(gelu_fast(v[0]), gelu_fast(v[1])), pack2bf(gelu_fast(v[2]), gelu_fast(v[3]))};
+          // (x sigma(quintic): the epilogue is VALU-bound -- 96 values per lane per chunk against 3 072 cycles of MFMAs)
+          const u32x2 o = {pack2bf(gelu_sig4(v[0]), gelu_sig4(v[1])), pack2bf(gelu_sig4(v[2]), gelu_sig4(v[3]))};
           *reinterpret_cast<u32x2*>(out + (long)tok * d + 16 * cb) = o;
         }
       }

@@ -41,10 +41,10 @@ int launch_mlp_pack(const void* w1_folded, const void* w2, const void* wqkv_fold
 int launch_mlp_fused(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
                      const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s,
                      const float* q_u = nullptr, const float* q_cb = nullptr, void* q_out = nullptr, int NQ = 0,
-                     float* x_next_out = nullptr, const float* bo = nullptr);
+                     float* x_next_out = nullptr, const float* bo = nullptr, bool keep_x_new = true);
 int launch_mlp_fused_final(const float* x, const void* ctx, float* x_mid, const float* ln_u, const float* ln_cb,
                            const void* Wt, const float* b2, const float* bo, const float* lnf_w, const float* lnf_b, float* y,
-                           long M, int d, int F, hipStream_t s);
+                           long M, int d, int F, hipStream_t s, bool keep_x_new = true);
 int launch_lnqkv_fused(const float* x, const float* q_u, const float* q_cb, const void* Wt, void* q_out, long M, int d,
                        int NQ, hipStream_t s);
 int launch_add_delta_f32(const float* x, const void* delta_bf16, float* out, long n, hipStream_t s);
@@ -611,7 +611,7 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
         const LayerW& Ln = e->layers[i + 1];
         // (x_next comes back in xc itself: xn only holds x_new, the block's intermediate residual stream)
         TR(TR_MLPQKV, launch_mlp_fused(xc, op ? ctx : d1, xn, L.u1, L.cb1, op ? L.wmlp_op : L.wmlp, L.b2, nullptr, M, d, F, s,
-                                       Ln.uqkv, Ln.cbqkv, qkv, 3 * d, nullptr, op ? L.bo : nullptr));
+                                       Ln.uqkv, Ln.cbqkv, qkv, 3 * d, nullptr, op ? L.bo : nullptr, /*keep_x_new=*/false));
         pending = nullptr;
         qkv_done = true;
         continue;
@@ -622,7 +622,7 @@ static int forward_impl(gww_encoder* e, const float* mel, int batch, int precisi
         // kernel (no bf16 delta, no second read of the residual stream, no LayerNorm launch); the pooled token is row
         // T - 1 of it
         TR(TR_MLPFIN, launch_mlp_fused_final(xc, ctx, xn, L.u1, L.cb1, L.wmlp_op, L.b2, L.bo, e->lnw, e->lnb, last_hidden, M, d,
-                                             F, s));
+                                             F, s, /*keep_x_new=*/false));
         if (last_token)
           GWW_HIP(hipMemcpy2DAsync(last_token, (size_t)d * 4, last_hidden + (size_t)(T - 1) * d, (size_t)T * d * 4, (size_t)d * 4,
                                    B, hipMemcpyDeviceToDevice, s));

@@ -74,16 +74,6 @@ __device__ __forceinline__ void vm_wait() {
 template <int I>
 using ic = std::integral_constant<int, I>;
 
-// x * sigmoid(p(x)), p an odd quintic fitted to the erf GELU (the fused block's form, mlp_fused.hip): |err| <= 2.6e-5,
-// 7 plain VALU operations + v_exp_f32 + v_rcp_f32 -- a third cheaper than the erf polynomial of gelu_fast
-__device__ __forceinline__ float gelu_sig4(float x) {
-  const float s = fminf(x * x, 64.0f);
-  float q = fmaf(s, 0.0010148164f, -0.1067791331f);
-  q = fmaf(s, q, -2.3011178f);
-  const float e = __builtin_amdgcn_exp2f(x * q);
-  return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
 }  // namespace
 
 template <int EPI>

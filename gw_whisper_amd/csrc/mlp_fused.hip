@@ -72,6 +72,16 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #else
 #define MF_NT ""
 #endif
+#ifndef GWW_MF_XNT
+#define GWW_MF_XNT 0   // 1: the XACC x request with the non-temporal hint too.  Measured 1.490 against 1.414 ms: a lane pair reads
+                       // 32 bytes of a row per instruction and the four instructions of a 32-column block share each row's
+                       // 128-byte line -- without the hint the line stays in the vector L1 for the other three
+#endif
+#if GWW_MF_XNT
+#define MF_XNT MF_NT
+#else
+#define MF_XNT ""
+#endif
 #ifndef GWW_MF_DMAGAP
 #define GWW_MF_DMAGAP 1   // (with SCHED) DMA pieces of a riding tile in the gaps the GELU schedule leaves empty (0: one per step)
 #endif
@@ -87,6 +97,17 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #define GWW_MF_NORM 1   // 1: the A operand is normalised once per panel, a^ = bf16((a - mean') rstd), so the fc1 / q,k,v outputs need
                         // only + cb (0: round 1's per-value LayerNorm algebra rstd (acc - mean' u) + cb: two more VALU
                         // instructions and an LDS read of u per activation value -- the GELU path is what bounds the main loop)
+#endif
+#ifndef GWW_MF_XACC
+#define GWW_MF_XACC 1   // (OP, MODE 1 / 3) round 4: the residual stream lives in the OUTPUT ACCUMULATORS for the whole block.  x is
+                        // requested straight into the 192 accumulator registers at kernel start (accumulator layout: a lane owns
+                        // half of ITS row), the out_proj GEMM accumulates on top (x_new = x + ctx W_o^T in fp32: the delta is no
+                        // longer rounded to bf16), fc2 accumulates on top of that (x_next), and both seams become register work:
+                        // row statistics in-lane + one cross-half add, the bf16 A operand by v_permlane32_swap (lane r and lane
+                        // r + 32 exchange their halves of a 32-column block: no LDS transpose), x_next / y stored from the
+                        // accumulator layout.  Gone: the x load of seam 1 in row order, the x_new store, its re-read in seam 2
+                        // (1.2 GB of the launch's 4.0 GB at B = 256 and two exposed HBM round trips per panel), 96 LDS
+                        // transposes per seam.  x_new is still written when the caller keeps it (training: x_mid).
 #endif
 constexpr int MF_AHEAD = GWW_MF_AHEAD;   // tiles in flight ahead of the one being computed
 // Ring: AHEAD + 1 slots of one 16-KiB tile, one s_barrier per tile.  (One barrier per two tiles with one more slot was
@@ -194,9 +215,10 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
                                                             int stagger_ticks, const float* __restrict__ q_u,
                                                             const float* __restrict__ q_cb,
                                                             unsigned short* __restrict__ q_out, int NQ,
-                                                            float* x_next, const float* __restrict__ bo) {
+                                                            float* x_next, const float* __restrict__ bo, int keep_x_new) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[MF_LDS];
   constexpr bool QKV = MODE == 1 || MODE == 2, LNQ = MODE == 2, FIN = MODE == 3;
+  constexpr bool XACC = GWW_MF_XACC && GWW_MF_NORM && GWW_MF_SCHED && OP && (MODE == 1 || MODE == 3);
   constexpr int MF_NST = MF_AHEAD + 1;
   float* lds_cb = reinterpret_cast<float*>(lds + MF_OFF_CB);
   float* lds_u = reinterpret_cast<float*>(lds + MF_OFF_U);
@@ -264,7 +286,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   }
   if (!GWW_MF_NORM && FIN) __syncthreads();
   if (!LNQ)
-    for (int i = tid; i < MF_D; i += MF_THREADS) lds_b2[i] = b2[i];
+    for (int i = tid; i < MF_D; i += MF_THREADS) lds_b2[i] = XACC ? b2[i] + bo[i] : b2[i];   // XACC: O holds x + ctx W_o^T + fc2, both biases are added when it is read
   if (OP)
     for (int i = tid; i < MF_D; i += MF_THREADS) lds_bo[i] = bo[i];
   if (FIN)   // gain / bias of the encoder's final LayerNorm (q_u / q_cb carry them in this mode), in the unused u table
@@ -287,6 +309,23 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   // prologue's stores) at worst waits for more than it needs.
 #pragma unroll
   for (int p = 0; p < MF_AHEAD; ++p) issue(p, p);
+  // accumulator layout of O: lane (r, hh) owns row m_base + r, columns 32 t + 8 cc + 4 hh .. + 3 in O[t][4 cc ..]
+  const long xrow_l = m_base + r < M ? m_base + r : M - 1;
+  const unsigned xoff = (unsigned)xrow_l * (unsigned)(MF_D * 4) + 16u * (unsigned)hh;
+  f32x4 xp[XACC ? MF_OT : 1][4];
+  if constexpr (XACC) {
+    // The residual stream goes straight INTO the accumulator file (48 loads of 16 bytes per lane, 32-byte row pieces
+    // per lane pair), in front of the ctx loads: loads retire in issue order, so the first counted ctx wait below also
+    // proves every x piece has landed -- long before the out_proj GEMM's first MFMA reads them as its C operand.  The four
+    // pieces of an accumulator tile are joined into O[t] BEHIND that wait (a register-sequence rename when hipcc's coalescer
+    // cooperates, sixteen v_accvgpr_mov otherwise -- either way on landed data; tools/audit_asm_preload.py, build()).
+#pragma unroll
+    for (int t = 0; t < MF_OT; ++t)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+        if (GWW_MF_ABL & 32) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(xp[t][cc][0]));   // (diagnostic: no x loads)
+        else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" MF_XNT : "=a"(xp[t][cc]) : "v"(xoff), "s"(X), "n"((32 * t + 8 * cc) * 4) : "memory");
+  }
   // ---- prologue: x_new = x + delta (written back), a = bf16(x_new - c), exact fp32 row statistics
   bf16x8 af[MF_KT * 4];
   float row_rstd, row_mean;
@@ -448,10 +487,20 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   for (int j = 0; j < 4; ++j) offq[j] = r * 128 + (((4 * hh + j) ^ ((r >> 1) & 7)) << 4);
 
   f32x16 sacc[4], oacc[MF_OT];
+  if constexpr (XACC) {   // the x pieces (landed: behind the prologue's ctx waits) become the accumulator tiles
 #pragma unroll
-  for (int t = 0; t < MF_OT; ++t)
+    for (int t = 0; t < MF_OT; ++t) {
+      asm volatile("" : "+a"(xp[t][0]), "+a"(xp[t][1]), "+a"(xp[t][2]), "+a"(xp[t][3]));
+      const auto lo = __builtin_shufflevector(xp[t][0], xp[t][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      const auto hi = __builtin_shufflevector(xp[t][2], xp[t][3], 0, 1, 2, 3, 4, 5, 6, 7);
+      oacc[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    }
+  } else {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) oacc[t][j] = 0.f;
+    for (int t = 0; t < MF_OT; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) oacc[t][j] = 0.f;
+  }
   u32x4 pf[4][2];   // bf16 operand fragments of fc2: pf[t][s] = gelu(S[t]) registers 8 s .. 8 s + 7
 
   // Activation piece p = 4 t + cc of chunk c: LayerNorm algebra + bias + GELU on registers 4 cc .. 4 cc + 3 of
@@ -878,6 +927,64 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       row_mean = stat[32 + r];
       asm volatile("" : "+v"(row_rstd), "+v"(row_mean)::"memory");
       };
+  // ---- XACC seam: O (+ bias) IS the new residual stream, in accumulator layout.  Pass A: optional store (x_new for the
+  // training path, x_next behind fc2), shifted row sums in-lane, one cross-half add.  Pass B: (v - mean) rstd -> bf16 pairs;
+  // lane r (hh = 0) owns columns 8 cc .. + 3 of every 32-block, lane r + 32 columns 8 cc + 4 .. + 7, and the A fragment
+  // af[4 S + cc] of lane (r, hh) is k = 64 S + 32 hh + 8 cc .. + 7: the low lane needs the partner's half of the EVEN block
+  // 2 S, the high lane the partner's half of the ODD block 2 S + 1 -- exactly one v_permlane32_swap per packed word pair
+  // (attention.hip's GWW_ATT_EPI16 epilogue uses the same exchange).  One rounding, no LDS, no second normalise pass.
+  auto seam_x = [&](const float* sb, float* dst) {
+    if constexpr (XACC) {
+    float s1 = 0.f, s2 = 0.f, csh = 0.f;
+#pragma unroll
+    for (int t = 0; t < MF_OT; ++t)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const float4 bv = *reinterpret_cast<const float4*>(sb + 32 * t + 8 * cc + 4 * hh);
+        f32x4 v = {oacc[t][4 * cc] + bv.x, oacc[t][4 * cc + 1] + bv.y, oacc[t][4 * cc + 2] + bv.z, oacc[t][4 * cc + 3] + bv.w};
+        if (dst && !(GWW_MF_ABL & 16)) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dst) + xoff + (32 * t + 8 * cc) * 4) = v;
+        if (t == 0 && cc == 0) {   // one shift per ROW: the low lane's first value, for both halves
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[0]), false, false);
+          csh = hh ? __uint_as_float(sw[0]) : v[0];   // (high lanes: [0] = the low lanes' operand)
+        }
+        v[0] -= csh; v[1] -= csh; v[2] -= csh; v[3] -= csh;
+        s1 += (v[0] + v[1]) + (v[2] + v[3]);
+        s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      }
+    {
+      const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
+      const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+      s1 = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+      s2 = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    }
+    const float mean_s = s1 * (1.0f / MF_D);
+    row_rstd = rsqrtf(fmaxf(s2 * (1.0f / MF_D) - mean_s * mean_s, 0.f) + 1e-5f);
+    row_mean = csh + mean_s;
+    const float nm = -row_mean * row_rstd;
+    // (a fence between the passes: without it hipcc keeps all 192 sums O + bias of pass A alive for pass B -- fifty spills)
+    asm volatile("" : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]), "+a"(oacc[3]), "+a"(oacc[4]), "+a"(oacc[5]), "+a"(oacc[6]),
+                      "+a"(oacc[7]), "+a"(oacc[8]), "+a"(oacc[9]), "+a"(oacc[10]), "+a"(oacc[11]));
+#pragma unroll
+    for (int S = 0; S < MF_KT; ++S)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const float4 be = *reinterpret_cast<const float4*>(sb + 64 * S + 8 * cc + 4 * hh);
+        const float4 bo_ = *reinterpret_cast<const float4*>(sb + 64 * S + 32 + 8 * cc + 4 * hh);
+        const f32x16& E = oacc[2 * S];
+        const f32x16& O = oacc[2 * S + 1];
+        const unsigned e0 = pack2bf(fmaf(E[4 * cc] + be.x, row_rstd, nm), fmaf(E[4 * cc + 1] + be.y, row_rstd, nm));
+        const unsigned e1 = pack2bf(fmaf(E[4 * cc + 2] + be.z, row_rstd, nm), fmaf(E[4 * cc + 3] + be.w, row_rstd, nm));
+        const unsigned o0 = pack2bf(fmaf(O[4 * cc] + bo_.x, row_rstd, nm), fmaf(O[4 * cc + 1] + bo_.y, row_rstd, nm));
+        const unsigned o1 = pack2bf(fmaf(O[4 * cc + 2] + bo_.z, row_rstd, nm), fmaf(O[4 * cc + 3] + bo_.w, row_rstd, nm));
+        // swap(x, y): x's upper 32 lanes <-> y's lower 32 lanes.  Low lanes: [0] own half of the even block, [1] the
+        // partner's; high lanes: [0] the partner's half of the odd block, [1] own
+        const auto w0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+        const auto w1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+        const u32x4 f = {w0[0], w1[0], w0[1], w1[1]};
+        af[4 * S + cc] = __builtin_bit_cast(bf16x8, f);
+      }
+      }
+  };
   if constexpr (OP) {
     // ======== out_proj in front of the block: O[n][m] = sum_k W_o[n][k] ctx[m][k], 3 n-tiles x 6 k-tiles of the q / k / v
     // tile format, accumulated into the (zeroed, still idle) output accumulators O[4 nt + u]
@@ -914,6 +1021,11 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     asm volatile("s_nop 15\n\ts_nop 15"
                  : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]), "+a"(oacc[3]), "+a"(oacc[4]), "+a"(oacc[5]), "+a"(oacc[6]),
                    "+a"(oacc[7]), "+a"(oacc[8]), "+a"(oacc[9]), "+a"(oacc[10]), "+a"(oacc[11]));
+    if constexpr (XACC) {
+      // x_new = x + ctx W_o^T + bo sits in O (bo is added on the fly): LN2 statistics and the fc1 operand straight from the
+      // registers; fc2 keeps accumulating on top of it
+      seam_x(lds_bo, (keep_x_new && !(GWW_MF_ABL & 256)) ? x_out : nullptr);   // (256: diagnostic, the ABI entry without x_new)
+    } else {
     // x_new = x + bf16(ctx W_o^T + bo): written to x_out, LN2 statistics, A fragments
     seam(X, x_out, lds_bo, [] {});
 #if GWW_MF_NORM
@@ -923,6 +1035,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     for (int t = 0; t < MF_OT; ++t)
 #pragma unroll
       for (int j = 0; j < 16; ++j) oacc[t][j] = 0.f;   // fc2 accumulates from zero
+    }
     TSTAMP(15);
   }
   if constexpr (!LNQ) {   // ======== the MLP stream (MODE 2 has none: straight to the q / k / v tail)
@@ -933,7 +1046,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       for (int q = 0; q < 4; ++q) preload_bias(t, t >> 1, q);
   }
   // G1(0): no GELU to carry yet; its first half is then computed in the open (once per 128 rows)
-  using IW = std::conditional_t<OP && !(GWW_MF_ABL & 32), I2, I1>;   // behind the out_proj seam: tiles 0 / 1 have landed
+  using IW = std::conditional_t<OP && !XACC && !(GWW_MF_ABL & 32), I2, I1>;   // behind the out_proj seam: tiles 0 / 1 have landed (XACC: its seam loads nothing, the ring waits are the regular ones)
   run_tile(MF_FL<0>{}, I0{}, I0{}, I0{}, IM{}, 0, 0, IM{}, 0, IW{});
   run_tile(MF_FL<1>{}, I0{}, I0{}, I1{}, IM{}, 0, 0, IM{}, 0, IW{});
   run_tile(MF_FL<2>{}, I0{}, I0{}, I2{}, IM{}, 0, 0, IM{}, 0, I1{});
@@ -981,7 +1094,52 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
                  : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]), "+a"(oacc[3]), "+a"(oacc[4]), "+a"(oacc[5]), "+a"(oacc[6]),
                    "+a"(oacc[7]), "+a"(oacc[8]), "+a"(oacc[9]), "+a"(oacc[10]), "+a"(oacc[11]));
   }   // ======== !LNQ
-  if constexpr (FIN) {
+  if constexpr (FIN && XACC) {
+    // ---- MODE 3 with the residual stream in O: x_fin = O + (b2 + bo); row statistics as in seam_x, then
+    // y = (x_fin - mean) rstd g + b goes to last_hidden_state from the accumulator layout (HF:modeling_whisper.py:642)
+    mf_wait_vmcnt<0>();   // the ring's re-reads issued past the end
+    float* y_out = reinterpret_cast<float*>(C);
+    float s1 = 0.f, s2 = 0.f, csh = 0.f;
+#pragma unroll
+    for (int t = 0; t < MF_OT; ++t)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const float4 bv = *reinterpret_cast<const float4*>(lds_b2 + 32 * t + 8 * cc + 4 * hh);
+        f32x4 v = {oacc[t][4 * cc] + bv.x, oacc[t][4 * cc + 1] + bv.y, oacc[t][4 * cc + 2] + bv.z, oacc[t][4 * cc + 3] + bv.w};
+        if (t == 0 && cc == 0) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[0]), false, false);
+          csh = hh ? __uint_as_float(sw[0]) : v[0];
+        }
+        v[0] -= csh; v[1] -= csh; v[2] -= csh; v[3] -= csh;
+        s1 += (v[0] + v[1]) + (v[2] + v[3]);
+        s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      }
+    {
+      const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
+      const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+      s1 = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+      s2 = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    }
+    const float mean_s = s1 * (1.0f / MF_D);
+    const float rstd = rsqrtf(fmaxf(s2 * (1.0f / MF_D) - mean_s * mean_s, 0.f) + 1e-5f);
+    const float mean = csh + mean_s;
+    // (a fence between the passes: without it hipcc keeps all 192 sums O + bias of pass A alive for pass B -- fifty spills)
+    asm volatile("" : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]), "+a"(oacc[3]), "+a"(oacc[4]), "+a"(oacc[5]), "+a"(oacc[6]),
+                      "+a"(oacc[7]), "+a"(oacc[8]), "+a"(oacc[9]), "+a"(oacc[10]), "+a"(oacc[11]));
+#pragma unroll
+    for (int t = 0; t < MF_OT; ++t)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int col = 32 * t + 8 * cc + 4 * hh;
+        const float4 bv = *reinterpret_cast<const float4*>(lds_b2 + col);
+        const float4 g4 = *reinterpret_cast<const float4*>(lds_u + col);
+        const float4 b4 = *reinterpret_cast<const float4*>(lds_u + MF_D + col);
+        const f32x4 y = {fmaf((oacc[t][4 * cc] + bv.x - mean) * rstd, g4.x, b4.x), fmaf((oacc[t][4 * cc + 1] + bv.y - mean) * rstd, g4.y, b4.y),
+                         fmaf((oacc[t][4 * cc + 2] + bv.z - mean) * rstd, g4.z, b4.z), fmaf((oacc[t][4 * cc + 3] + bv.w - mean) * rstd, g4.w, b4.w)};
+        // rows past M are clamped duplicates of row M - 1: every duplicate stores the same value
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(y_out) + xoff + (32 * t + 8 * cc) * 4) = y;
+      }
+  } else if constexpr (FIN) {
     // ---- MODE 3, the LAST block of the encoder: the epilogue is the final LayerNorm (HF:modeling_whisper.py:642).
     // x_fin = x_new + bf16(fc2 output + b2) is formed exactly as the second seam forms x_next (same roundings as the
     // stand-alone delta + LayerNorm kernels), but all 48 row pieces of the panel stay in registers -- the accumulator
@@ -1107,7 +1265,11 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     // prologue), written to x_next (== x_out, i.e. IN PLACE, on the inference path; a buffer of its own on the training
     // path, which keeps x_new as x_mid), and shifted / measured / packed into the A fragments of k-tile np.
     // The tiles already in flight are older than these loads: hipcc's own vmcnt waits retire them first.
-    if constexpr (!LNQ) {   // the seam (MODE 2: the prologue already produced the normalised operand of LN1)
+    if constexpr (XACC) {
+      // x_next = O + (b2 + bo), stored from the accumulator layout (48 stores per lane, all lanes live: the first two tail
+      // tiles count them), LN1 statistics and the q / k / v operand from the registers
+      seam_x(lds_b2, x_next);
+    } else if constexpr (!LNQ) {   // the seam (MODE 2: the prologue already produced the normalised operand of LN1)
       seam(x_out, x_next, lds_b2, [] {});
 #if GWW_MF_NORM
     normalise_af();
@@ -1308,6 +1470,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         // then stay in flight
         constexpr int TAIL_ST = (GWW_MF_ABL & 3) ? 0 : 8;   // output stores per n-tile in the vmcnt queue
         if (GWW_MF_ABL & 4) {}
+        else if (XACC && nt == 0 && kt <= MF_AHEAD - 2) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + ((GWW_MF_ABL & 16) ? 0 : 4 * MF_OT)>();   // the seam's 48 x_next stores are younger than the awaited pieces
         else if (!LNQ && !(GWW_MF_ABL & 32) && nt == 0 && kt <= MF_AHEAD - 2) {}   // landed before the seam's loads (above)
         else if (nt > 0 && kt <= MF_AHEAD - 2) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + TAIL_ST>();
         else mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2)>();
@@ -1520,7 +1683,8 @@ int launch_mlp_pack(const void* w1_folded, const void* w2, const void* wqkv_fold
 // (launch_mlp_pack(..., wo)): x_out = x + bf16(ctx W_o^T + bo), then the block as above.
 int launch_mlp_fused(const float* x, const void* delta, float* x_out, const float* ln_u, const float* ln_cb,
                      const void* Wt, const float* b2, void* C, long M, int d, int F, hipStream_t s,
-                     const float* q_u, const float* q_cb, void* q_out, int NQ, float* x_next_out, const float* bo) {
+                     const float* q_u, const float* q_cb, void* q_out, int NQ, float* x_next_out, const float* bo,
+                     bool keep_x_new = true) {
   GWW_REQUIRE(x && delta && x_out && ln_u && ln_cb && Wt && b2, "mlp_fused: NULL operand");
   GWW_REQUIRE(d == MF_D, "mlp_fused: built for d_model = 384 (got %d)", d);
   GWW_REQUIRE(F % 128 == 0 && F > 0 && F <= MF_FMAX, "mlp_fused: ffn = %d must be a multiple of 128, <= 1536", F);
@@ -1539,7 +1703,7 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
   const int stagger = panels >= 512 ? stagger_env : 0;
 #define GWW_MF_LAUNCH(QQ, OO, ...)                                                                                        \
   hipLaunchKernelGGL((k_mlp_fused<QQ, OO>), dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)delta, \
-                     x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger, __VA_ARGS__, bo)
+                     x_out, ln_u, ln_cb, (const unsigned short*)Wt, b2, (unsigned short*)C, M, F, stagger, __VA_ARGS__, bo, keep_x_new ? 1 : 0)
   if (qkv) {
     // x_next goes to its own buffer (training: the saved activations) or back over x, whose rows each workgroup has
     // finished reading long before it writes them; never over x_out: the seam's unmasked stores of the clamped rows past M
@@ -1562,7 +1726,7 @@ int launch_mlp_fused(const float* x, const void* delta, float* x_out, const floa
 // != x, != y) receives the block's intermediate residual stream.  Wt = launch_mlp_pack(w1_folded, w2, NULL, ., wo).
 int launch_mlp_fused_final(const float* x, const void* ctx, float* x_mid, const float* ln_u, const float* ln_cb,
                            const void* Wt, const float* b2, const float* bo, const float* lnf_w, const float* lnf_b, float* y,
-                           long M, int d, int F, hipStream_t s) {
+                           long M, int d, int F, hipStream_t s, bool keep_x_new = true) {
   GWW_REQUIRE(x && ctx && x_mid && ln_u && ln_cb && Wt && b2 && bo && lnf_w && lnf_b && y, "mlp_fused_final: NULL operand");
   GWW_REQUIRE(d == MF_D, "mlp_fused_final: built for d_model = 384 (got %d)", d);
   GWW_REQUIRE(F % 128 == 0 && F > 0 && F <= MF_FMAX, "mlp_fused_final: ffn = %d must be a multiple of 128, <= 1536", F);
@@ -1573,7 +1737,7 @@ int launch_mlp_fused_final(const float* x, const void* ctx, float* x_mid, const 
   if (M == 0) return GWW_OK;
   hipLaunchKernelGGL((k_mlp_fused<3, true>), dim3((unsigned)cdiv(M, MF_BM)), dim3(MF_THREADS), 0, s, x, (const unsigned short*)ctx,
                      x_mid, ln_u, ln_cb, (const unsigned short*)Wt, b2, reinterpret_cast<unsigned short*>(y), M, F, 0, lnf_w,
-                     lnf_b, (unsigned short*)nullptr, 0, (float*)nullptr, bo);
+                     lnf_b, (unsigned short*)nullptr, 0, (float*)nullptr, bo, keep_x_new ? 1 : 0);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }
@@ -1592,7 +1756,7 @@ int launch_lnqkv_fused(const float* x, const float* q_u, const float* q_cb, cons
   hipLaunchKernelGGL((k_mlp_fused<2, false>), dim3((unsigned)panels), dim3(MF_THREADS), 0, s, x, (const unsigned short*)nullptr,
                      (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const unsigned short*)Wt,
                      (const float*)nullptr, (unsigned short*)nullptr, M, 0, 0, q_u, q_cb, (unsigned short*)q_out, NQ,
-                     (float*)nullptr, (const float*)nullptr);
+                     (float*)nullptr, (const float*)nullptr, 0);
   GWW_LAUNCH_CHECK();
   return GWW_OK;
 }

@@ -644,12 +644,17 @@ def test_attn_out_mlp_final_layernorm_against_fp64(T, gww, M):
     # the delta carries bf16 rounding (2^-8 relative) and bf16-operand error; LayerNorm divides by the row's sigma (~2.5)
     np.testing.assert_allclose(got, ref, atol=3e-2, rtol=0)
     assert np.sqrt(((got - ref) ** 2).mean()) < 4e-3
-    # ... and bit for bit what the stand-alone kernels give on the same operands: the bf16 delta + the LayerNorm kernel
+    # Since round 4 the residual stream stays in the kernel's output accumulators (fp32): neither delta is rounded to bf16 on
+    # its way into it, so the result is CLOSER to fp64 than the stand-alone kernels' (bf16 delta + LayerNorm kernel), which it
+    # used to reproduce bit for bit -- now it must agree with them to the two delta roundings they carry
     delta, x_mid2 = ops.attn_out_mlp_fused(c(o["x"]), c(o["ctx"]).bfloat16(), c(o["wo"]).bfloat16(), c(o["bo"]), w1f,
                                            c(o["w2"]).bfloat16(), u, cb, c(o["b2"]))
-    assert T.equal(x_mid2, x_mid_dev)
+    dx = (x_mid2 - x_mid_dev).abs().cpu().numpy()
+    assert (dx <= np.abs(x_mid - o["x"]) * 2.0 ** -8 + 1e-3).all(), dx.max()
     unfused = ops.layernorm(x_mid2 + delta.float(), c(o["lw1"]), c(o["lb1"]))
-    assert (y - unfused).abs().max().item() < 2e-5
+    assert (y - unfused).abs().max().item() < 3e-2
+    ref64 = oenc.layer_norm(x_mid + mlp, o["lw1"], o["lb1"])
+    assert np.sqrt(((got - ref64) ** 2).mean()) <= np.sqrt(((unfused.cpu().numpy() - ref64) ** 2).mean()) * 1.05 + 1e-4
 
 
 @pytest.mark.parametrize("M", [128, 1500, 777, 70000])
