@@ -72,6 +72,15 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #else
 #define MF_NT ""
 #endif
+#ifndef GWW_MF_XLDS
+#define GWW_MF_XLDS 0   // 1: XACC's x_next / x_new / y leave through the wave-private LDS slices in ROW order (whole 128-byte lines, 8
+                        // rows per store instruction) instead of from the accumulator layout (32-byte row pieces per lane pair).
+                        // Measured 1.449 against 1.438 ms: the 0.08 ms the 48 stores of a panel cost (ABL=272) is not their
+                        // request count -- it is the in-order vmcnt queue again (the third tail tile's ring wait needs them retired)
+#endif
+#ifndef GWW_MF_XSTNT
+#define GWW_MF_XSTNT 0   // XACC: x_next / y stores with the non-temporal hint
+#endif
 #ifndef GWW_MF_XNT
 #define GWW_MF_XNT 0   // 1: the XACC x request with the non-temporal hint too.  Measured 1.490 against 1.414 ms: a lane pair reads
                        // 32 bytes of a row per instruction and the four instructions of a 32-column block share each row's
@@ -674,7 +683,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     // A four-stage ring makes the stage of every tile of the unrolled 12-tile body a compile-time constant (flat tile
     // index mod 4): every fragment address is then base register + immediate (no v_or_b32 per read: 8 cycles each
     // beside an MFMA, tools/ubench/mfma_gap.hip) and the DMA destination needs no wrap-around arithmetic.
-    constexpr int ST = MF_NST == 4 ? ((decltype(flat_c)::value + OP_TILES) & 3) : -1;
+    constexpr int ST = (12 % MF_NST == 0) ? ((decltype(flat_c)::value + OP_TILES) % MF_NST) : -1;   // (the unrolled body is 12 tiles: static for 4- and 6-stage rings)
     if (ST >= 0) stage = ST;
     if constexpr (!(GWW_MF_EXP & 64)) {   // (64: diagnostic, no ring wait / barrier -- only meaningful together with 1)
       if (!NOWAIT) mf_wait_vmcnt<MF_GL * (MF_AHEAD - 2)>();
@@ -942,7 +951,22 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       for (int cc = 0; cc < 4; ++cc) {
         const float4 bv = *reinterpret_cast<const float4*>(sb + 32 * t + 8 * cc + 4 * hh);
         f32x4 v = {oacc[t][4 * cc] + bv.x, oacc[t][4 * cc + 1] + bv.y, oacc[t][4 * cc + 2] + bv.z, oacc[t][4 * cc + 3] + bv.w};
-        if (dst && !(GWW_MF_ABL & 16)) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dst) + xoff + (32 * t + 8 * cc) * 4) = v;
+        if (dst && !(GWW_MF_ABL & 16)) {
+          if (GWW_MF_XLDS) {   // into the slice in accumulator layout (rows 144 bytes apart: conflict-free for the 16-lane groups)
+            *reinterpret_cast<f32x4*>(slice0 + (t & 1) * (MF_WAVES * MF_SLICE_BYTES) + r * MF_SLICE_STRIDE + (8 * cc + 4 * hh) * 4) = v;
+          } else {
+            f32x4* const sp = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dst) + xoff + (32 * t + 8 * cc) * 4);
+            if (GWW_MF_XSTNT) __builtin_nontemporal_store(v, sp);
+            else *sp = v;
+          }
+        }
+        if (GWW_MF_XLDS && dst && !(GWW_MF_ABL & 16) && cc == 3) {   // the 32-column block back in row order: 8 rows x 128 bytes per store
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(slice0 + (t & 1) * (MF_WAVES * MF_SLICE_BYTES) + (8 * i + crow) * MF_SLICE_STRIDE + cchunk * 16);
+            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dst) + (unsigned)grow[i] * (unsigned)(MF_D * 4) + 16u * (unsigned)cchunk + t * 128) = u;
+          }
+        }
         if (t == 0 && cc == 0) {   // one shift per ROW: the low lane's first value, for both halves
           const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[0]), false, false);
           csh = hh ? __uint_as_float(sw[0]) : v[0];   // (high lanes: [0] = the low lanes' operand)
@@ -988,7 +1012,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   if constexpr (OP) {
     // ======== out_proj in front of the block: O[n][m] = sum_k W_o[n][k] ctx[m][k], 3 n-tiles x 6 k-tiles of the q / k / v
     // tile format, accumulated into the (zeroed, still idle) output accumulators O[4 nt + u]
-    static_assert(MF_NST == 4, "OP mode relies on the four-stage ring");
+    static_assert(12 % MF_NST == 0, "OP mode relies on a ring whose depth divides the 12-tile body (4 or 6 stages)");
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
 #pragma unroll
@@ -996,7 +1020,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         const int itile = nt * MF_KT + kt;               // compile-time: the stage is static
         if (!(GWW_MF_ABL & 128)) mf_wait_vmcnt<MF_GL * (MF_AHEAD - 2)>();
         __builtin_amdgcn_s_barrier();
-        const int st = itile & 3, st_next = (itile + 1) & 3, dma_st = (itile + MF_AHEAD) & 3;
+        const int st = itile % MF_NST, st_next = (itile + 1) % MF_NST, dma_st = (itile + MF_AHEAD) % MF_NST;
         const int dma_tile = itile + MF_AHEAD < total ? itile + MF_AHEAD : total - 1;
         const bool last = itile == OP_TILES - 1;          // its last step prefetches the first fc1 tile's fragments
 #pragma unroll
@@ -1016,7 +1040,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       }
     }
     it = OP_TILES;
-    stage = OP_TILES & 3;
+    stage = OP_TILES % MF_NST;
     TSTAMP(14);
     asm volatile("s_nop 15\n\ts_nop 15"
                  : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]), "+a"(oacc[3]), "+a"(oacc[4]), "+a"(oacc[5]), "+a"(oacc[6]),
@@ -1137,7 +1161,17 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
         const f32x4 y = {fmaf((oacc[t][4 * cc] + bv.x - mean) * rstd, g4.x, b4.x), fmaf((oacc[t][4 * cc + 1] + bv.y - mean) * rstd, g4.y, b4.y),
                          fmaf((oacc[t][4 * cc + 2] + bv.z - mean) * rstd, g4.z, b4.z), fmaf((oacc[t][4 * cc + 3] + bv.w - mean) * rstd, g4.w, b4.w)};
         // rows past M are clamped duplicates of row M - 1: every duplicate stores the same value
-        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(y_out) + xoff + (32 * t + 8 * cc) * 4) = y;
+        if (GWW_MF_XLDS) {
+          *reinterpret_cast<f32x4*>(slice0 + (t & 1) * (MF_WAVES * MF_SLICE_BYTES) + r * MF_SLICE_STRIDE + (8 * cc + 4 * hh) * 4) = y;
+          if (cc == 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const f32x4 u = *reinterpret_cast<const f32x4*>(slice0 + (t & 1) * (MF_WAVES * MF_SLICE_BYTES) + (8 * i + crow) * MF_SLICE_STRIDE + cchunk * 16);
+              *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(y_out) + (unsigned)grow[i] * (unsigned)(MF_D * 4) + 16u * (unsigned)cchunk + t * 128) = u;
+            }
+          }
+        } else if (GWW_MF_XSTNT) __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(reinterpret_cast<char*>(y_out) + xoff + (32 * t + 8 * cc) * 4));
+        else *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(y_out) + xoff + (32 * t + 8 * cc) * 4) = y;
       }
   } else if constexpr (FIN) {
     // ---- MODE 3, the LAST block of the encoder: the epilogue is the final LayerNorm (HF:modeling_whisper.py:642).
@@ -1333,7 +1367,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
       constexpr int FLAT = decltype(flat_c)::value, PAR = decltype(par_c)::value, IDX3 = decltype(idx3_c)::value;
       constexpr int RM = decltype(mode_c)::value, EXTRA = decltype(extra_c)::value;
       constexpr bool NOWAIT = decltype(nowait_c)::value != 0;
-      constexpr int ST = MF_NST == 4 ? ((FLAT + OP_TILES) & 3) : -1;   // (6 F / 64 MLP tiles in front: a multiple of 4)
+      constexpr int ST = (12 % MF_NST == 0) ? ((FLAT + OP_TILES) % MF_NST) : -1;   // (6 F / 64 MLP tiles in front: a multiple of 4)
       if (ST >= 0) stage = ST;
       if (!(GWW_MF_ABL & 4)) {
         if (!NOWAIT) mf_wait_vmcnt<MF_GL*(MF_AHEAD - 2) + ((GWW_MF_ABL & 3) ? 0 : EXTRA)>();
