@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void k_attn_rowdot(const unsigned short* __res
     const long bidx = row / T;
     const int t = (int)(row - bidx * T);
     D[(bidx * H + h) * T + t] = s;
-    if (any) atomicOr(nz + (bidx * H + h) * ((T + KB - 1) / KB) + t / KB, 1u);
+    // (a plain store: the flags are zeroed before the launch and every writer writes the same 1 -- 64 rows share a flag, and
+    //  600 k device-scope atomics on 9 k addresses were half of this kernel's time)
+    if (any) nz[(bidx * H + h) * ((T + KB - 1) / KB) + t / KB] = 1u;
   }
 }
 

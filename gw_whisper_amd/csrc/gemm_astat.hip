@@ -300,6 +300,21 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* Aany, 
     const int nn = nt0 + nti;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+      // EPI_DGELU: the incoming-gradient lines of this half are requested HERE, in front of the half's gelu' arithmetic (~1 300
+      // VALU instructions), and awaited behind it.  As plain loads next to their use (round 3) hipcc's vmcnt(0) in front of
+      // the multiply drained the six weight tiles in flight twice per n-tile with nothing to do meanwhile -- as long as the
+      // n-tile's MFMAs.  (asm: hipcc sinks a plain load back to its use.)
+      constexpr bool G_EARLY = EPI == EPI_DGELU && KT <= 6;   // (K = 512: the 16 extra live registers spill)
+      u32x4 gq[4];
+      if constexpr (G_EARLY) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const long orow = m_base + 8 * i + crow;
+          const long mrow = orow < M ? orow : M - 1;
+          const unsigned short* gp = delta + mrow * N + nn * AS_BN + 64 * half + 8 * cchunk;
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gq[i]) : "v"(gp) : "memory");
+        }
+      }
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int t = 2 * half + tt;
@@ -329,6 +344,8 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* Aany, 
           acc[t][4 * c] = 0.f; acc[t][4 * c + 1] = 0.f; acc[t][4 * c + 2] = 0.f; acc[t][4 * c + 3] = 0.f;
         }
       }
+      if constexpr (G_EARLY)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(gq[0]), "+v"(gq[1]), "+v"(gq[2]), "+v"(gq[3]));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         u32x4 u = *reinterpret_cast<const u32x4*>(slice + (8 * i + crow) * AS_SLICE_STRIDE + cchunk * 16);
@@ -344,8 +361,13 @@ __global__ __launch_bounds__(AS_THREADS, 1) void k_gemm_astat(const void* Aany, 
         unsigned short* dst = c_panel_rows ? C + ((long)(2 * nn + half) * c_panel_rows + orow) * 64 + 8 * cchunk
                                            : C + orow * N + nn * AS_BN + 64 * half + 8 * cchunk;
         if constexpr (EPI == EPI_DGELU) {   // times the incoming gradient (whole-line loads of the same [M, N] layout)
-          const long mrow = orow < M ? orow : M - 1;
-          const u32x4 g = *reinterpret_cast<const u32x4*>(delta + mrow * N + nn * AS_BN + 64 * half + 8 * cchunk);
+          u32x4 g;
+          if constexpr (G_EARLY) {
+            g = gq[i];
+          } else {
+            const long mrow = orow < M ? orow : M - 1;
+            g = *reinterpret_cast<const u32x4*>(delta + mrow * N + nn * AS_BN + 64 * half + 8 * cchunk);
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             u[q] = pack2bf(bf2f((unsigned short)(u[q] & 0xffff)) * bf2f((unsigned short)(g[q] & 0xffff)),
