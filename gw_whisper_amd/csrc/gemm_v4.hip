@@ -208,7 +208,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
   auto epi_quadrant = [&](auto ah_c, auto wh_c, long m0, int nn, int pre, long m0n, int nnn) {
     constexpr int ah = decltype(ah_c)::value, wh = decltype(wh_c)::value;
     f32x4 bvj[4];
-    {
+    if constexpr (!CONV2) {   // (conv2 reads its bias tile by tile: the 16 registers hold the position rows there)
       const unsigned ba = (unsigned)(unsigned long long)(lds_ptr)(lds_bias + nn * 256 + wh * 128 + wc * 64 + (lane >> 4) * 4);
       asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
                    "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
@@ -257,20 +257,22 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16_v4(const unsigned short* _
         float* const orow = live ? Cf + ((long)b * (rows_per_batch - 1) + t) * n_real : dump;
         const float* prow = pos + (long)(live ? t : 0) * n_real;
         const int col0 = cbase - cfold + (lane >> 4) * 4;
-        // the position rows are requested FIRST: the GELU arithmetic of the 16 values below (about 0.5 us) covers their
-        // wait, which -- loads retire in issue order -- is also a wait for the half-tiles requested before them
+        // Round 4: ONE exposed round trip per quadrant instead of four.  The position rows of this 16-row group (4 vectors) are
+        // requested first; the GELU of all four column tiles runs IN PLACE in the accumulator registers meanwhile (36 VALU
+        // operations per lane and tile: ~0.6 us, the latency of an L2 hit); then add + store.  (Two tiles at a time with the
+        // wait right behind 0.2 us of arithmetic -- round 3's form, 8 registers of position values instead of 16 -- left every
+        // pair waiting ~0.8 us with the partner wave's MFMA section long over.)
+        f32x4 pv[4];
 #pragma unroll
-        for (int jp = 0; jp < 4; jp += 2) {   // (two column tiles at a time: 8 registers of position values live, not 16)
-          f32x4 pv[2];
+        for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const f32x4*>(prow + col0 + j * 16);
 #pragma unroll
-          for (int u = 0; u < 2; ++u) pv[u] = *reinterpret_cast<const f32x4*>(prow + col0 + (jp + u) * 16);
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const f32x4 a = acc[ah][wh][i][jp + u] + bvj[jp + u];
-            const f32x4 g = {gelu_sig4(a[0]), gelu_sig4(a[1]), gelu_sig4(a[2]), gelu_sig4(a[3])};   // (9 instead of 16 VALU operations per value)
-            *reinterpret_cast<f32x4*>(orow + col0 + (jp + u) * 16) = g + pv[u];
-          }
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 bj = *reinterpret_cast<const f32x4*>(lds_bias + nn * 256 + wh * 128 + wc * 64 + (lane >> 4) * 4 + j * 16);
+          const f32x4 a = acc[ah][wh][i][j] + bj;
+          acc[ah][wh][i][j] = f32x4{gelu_sig4(a[0]), gelu_sig4(a[1]), gelu_sig4(a[2]), gelu_sig4(a[3])};
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(orow + col0 + j * 16) = acc[ah][wh][i][j] + pv[j];
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

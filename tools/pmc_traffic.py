@@ -17,7 +17,7 @@ CLASSES = [
     ("k_mlp_fused<1", "mlp_fused+next_ln_qkv"), ("k_mlp_fused<0", "mlp_fused(ln+fc1+gelu+fc2)"),
     ("k_mlp_fused<3", "mlp_fused+final_layernorm"),
     ("k_mlp_fused<2", "ln+qkv_proj"),
-    ("k_attention_", "attention"), ("k_gemm_bf16_v4<3", "conv2_gelu_pos"), ("k_gemm_fulln<3", "conv2_gelu_pos"), ("k_gemm_astat<4", "conv1_gelu"),
+    ("k_attention_", "attention"), ("k_gemm_bf16_v4<3", "conv2_gelu_pos"), ("k_gemm_fulln<3", "conv2_gelu_pos"), ("k_conv1_mel", "conv1_gelu"), ("k_gemm_astat<4", "conv1_gelu"),
     ("k_gemm_astat<0, 1", "ln+qkv_proj"), ("k_gemm_astat<0, 0", "out_proj"), ("k_mel_to_tokens", "mel_to_tokens"),
     ("k_layernorm<", "final_layernorm"),
 ]
