@@ -15,18 +15,36 @@
 // read both by rows and transposed are kept as two LDS images (chunk-XOR resp. bit-6-XOR swizzle).
 #include "common.h"
 
+#include <type_traits>
+
 namespace gww {
 
 namespace {
 constexpr int DH = 64, TB = 128, KB = 64;
+#ifndef GWW_ATTBWD_DMA
+#define GWW_ATTBWD_DMA 1   // round 4: k_attn_bwd_dq stages K / V by LDS-DMA (no staging registers, no ds_write_b128) and keeps ONE
+                           // image of K that serves the row reads of S = K Q^T and the transposed reads of dQ = dS K (dual_off
+                           // below): 32 KB of LDS.  Measured (tools/attbwd_exp.py, rowdot + dq + dkv at B = 64): 1.114 -> 1.078 ms
+                           // at two workgroups per CU; three per CU (168 registers: the accumulator start values have to go and 15
+                           // registers still spill) 1.086 -- not kept
+#endif
 #ifndef GWW_ATTBWD_DQ_WAVES
-#define GWW_ATTBWD_DQ_WAVES 2   // workgroups per CU of k_attn_bwd_dq (3: 168 registers, 12 bytes of scratch; 48 KB of LDS each)
+#define GWW_ATTBWD_DQ_WAVES 2   // workgroups per CU of k_attn_bwd_dq
 #endif
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr int TILE_BYTES = KB * DH * 2;   // 8 KB
 
 __device__ __forceinline__ int row_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int tr_off(int row, int colbyte) { return row * 128 + (colbyte ^ (((row >> 1) & 1) << 6)); }
+// One image of a row-major [64][64] bf16 tile for BOTH access patterns: 16-byte chunk c of row R sits at c ^ dual_x(R),
+// dual_x = (k & 1) << 2 | k >> 1 with k = (R >> 1) & 7.
+//  * ds_read_b128 row reads (16 lanes = rows R .. R + 15 of one chunk): the 8 values of k are a permutation of 0 .. 7, the
+//    two rows of a k differ in bit 7 of the address -> 16 distinct 16-byte slots of the 256-byte bank sweep;
+//  * ds_read_b64_tr_b16 (32 lanes = 4 rows x 64 bytes): rows R, R + 1 differ in bit 7, the row pairs (R, R + 1) / (R + 2, R + 3)
+//    in bit 6 (k & 1 goes to chunk bit 2) and the lanes of a row fill 64 contiguous bytes -> 32 distinct 8-byte slots.
+__device__ __forceinline__ int dual_x(int row) { const int k = (row >> 1) & 7; return ((k & 1) << 2) | (k >> 1); }
+__device__ __forceinline__ int dual_off(int row, int chunk) { return row * 128 + ((chunk ^ dual_x(row)) << 4); }
+__device__ __forceinline__ int dual_tr_off(int row, int colbyte) { return row * 128 + (colbyte ^ (dual_x(row) << 4)); }
 
 __device__ __forceinline__ bf16x8 cvt8(const f32x16& a, int base) {
   bf16x8 r;
@@ -45,6 +63,19 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int row0, i
   const int r = row0 + 4 * hh + tr_q;
   const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + tr_off(r, cb)));
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + tr_off(r + 8, cb)));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+__device__ __forceinline__ bf16x8 tr_frag_dual(const unsigned char* tile, int row0, int n, int lane) {
+  typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+  const int hh = lane >> 5;
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+  const int cb = 64 * n + (((lane & 31) >> 4) * 16 + 4 * tr_p) * 2;
+  const int r = row0 + 4 * hh + tr_q;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + dual_tr_off(r, cb)));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + dual_tr_off(r + 8, cb)));
   bf16x8 f;
   f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
   f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -105,11 +136,15 @@ __global__ __launch_bounds__(256, GWW_ATTBWD_DQ_WAVES) void k_attn_bwd_dq(const 
                                                         unsigned short* __restrict__ dqkv, int T, int H,
                                                         int q_tiles, const unsigned int* __restrict__ nz,
                                                         float ssc, float gsc) {
-  // per stage: K row image, K transposed-read image, V row image
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 3 * TILE_BYTES];   // 48 KB
-  auto Kr = [&](int buf) -> unsigned char* { return lds + (buf * 3 + 0) * TILE_BYTES; };
-  auto Kt = [&](int buf) -> unsigned char* { return lds + (buf * 3 + 1) * TILE_BYTES; };
-  auto Vr = [&](int buf) -> unsigned char* { return lds + (buf * 3 + 2) * TILE_BYTES; };
+  constexpr bool DMA = GWW_ATTBWD_DMA != 0;
+  // per stage: K row image, K transposed-read image, V row image (DMA: one dual-use K image + the V row image)
+  constexpr int IMGS = DMA ? 2 : 3;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * IMGS * TILE_BYTES];   // 48 KB (DMA: 32 KB)
+  auto Kr = [&](int buf) -> unsigned char* { return lds + (buf * IMGS + 0) * TILE_BYTES; };
+  auto Kt = [&](int buf) -> unsigned char* { return lds + (buf * IMGS + (DMA ? 0 : 1)) * TILE_BYTES; };
+  auto Vr = [&](int buf) -> unsigned char* { return lds + (buf * IMGS + IMGS - 1) * TILE_BYTES; };
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* g_ptr;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware work order (attention.hip): the query tiles of one (b, h) stream the same K / V -- keep them on one XCD
@@ -157,6 +192,7 @@ __global__ __launch_bounds__(256, GWW_ATTBWD_DQ_WAVES) void k_attn_bwd_dq(const 
   }
   u32x4 rk[2], rv[2];
   auto gload = [&](int kt) {
+    if constexpr (DMA) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int key = kt * KB + st_row[i];
@@ -166,11 +202,48 @@ __global__ __launch_bounds__(256, GWW_ATTBWD_DQ_WAVES) void k_attn_bwd_dq(const 
     }
   };
   auto lstore = [&](int buf) {
+    if constexpr (DMA) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       *reinterpret_cast<u32x4*>(Kr(buf) + row_off(st_row[i], st_chunk[i])) = rk[i];
       *reinterpret_cast<u32x4*>(Kt(buf) + tr_off(st_row[i], st_chunk[i] * 16)) = rk[i];
       *reinterpret_cast<u32x4*>(Vr(buf) + row_off(st_row[i], st_chunk[i])) = rv[i];
+    }
+  };
+  // DMA: piece j of wave w = rows 8 (2 w + j) .. + 7 of the tile, 16 bytes per lane (position lane & 7 of row lane >> 3); the
+  // images stay lane-linear in LDS and the swizzles are applied to the per-lane SOURCE chunk (an XOR is its own inverse).
+  // Rows past T - 1 read row T - 1 (their scores are masked / their dS rows multiply nothing that is kept).
+  // (32-bit per-lane byte offsets + a wave-uniform tile base: 64-bit pointers per piece spilled at three workgroups per CU)
+  unsigned koff[2], voff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 8 * (2 * wave + j) + (lane >> 3), pos = lane & 7;
+    koff[j] = (unsigned)(row * (int)rs * 2 + ((pos ^ dual_x(row)) << 4));
+    voff[j] = (unsigned)(row * (int)rs * 2 + ((pos ^ ((row >> 1) & 7)) << 4));
+  }
+  auto dma = [&](int kt, int buf) {
+    if constexpr (!DMA) return;
+    const unsigned char* kb = reinterpret_cast<const unsigned char*>(kp + (long)kt * KB * rs);
+    const unsigned char* vb = reinterpret_cast<const unsigned char*>(vp + (long)kt * KB * rs);
+    unsigned char* dk = Kr(buf) + 2 * wave * 1024;
+    unsigned char* dv = Vr(buf) + 2 * wave * 1024;
+    if ((kt + 1) * KB <= T) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        __builtin_amdgcn_global_load_lds((g_ptr)(kb + koff[j]), (lds_ptr)(dk + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((g_ptr)(vb + voff[j]), (lds_ptr)(dv + j * 1024), 16, 0, 0);
+      }
+    } else {   // ragged last tile: rows past T - 1 read row T - 1
+      const int last_row = T - 1 - kt * KB;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = 8 * (2 * wave + j) + (lane >> 3), pos = lane & 7;
+        const int rc = row < last_row ? row : last_row;
+        const unsigned ko = (unsigned)(rc * (int)rs * 2 + ((pos ^ dual_x(row)) << 4));
+        const unsigned vo = (unsigned)(rc * (int)rs * 2 + ((pos ^ ((row >> 1) & 7)) << 4));
+        __builtin_amdgcn_global_load_lds((g_ptr)(kb + ko), (lds_ptr)(dk + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((g_ptr)(vb + vo), (lds_ptr)(dv + j * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -183,21 +256,33 @@ __global__ __launch_bounds__(256, GWW_ATTBWD_DQ_WAVES) void k_attn_bwd_dq(const 
   const int n_kt = (T + KB - 1) / KB;
   // the row constants as accumulator start values (the query sits on the lane: all 16 registers hold the same value)
   f32x16 c_lse, c_D;
+  // (at three workgroups per CU = 168 registers they are subtracted per element instead: 32 registers for 64 v_sub per tile)
+  constexpr bool CD = L2Q && GWW_ATTBWD_DQ_WAVES < 3;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { c_lse[j] = L2Q ? -lse_q : 0.f; c_D[j] = L2Q ? -D_q : 0.f; }
+  for (int j = 0; j < 16; ++j) { c_lse[j] = CD ? -lse_q : 0.f; c_D[j] = CD ? -D_q : 0.f; }
   gload(0);
   lstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < n_kt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < n_kt) gload(kt + 1);
+  dma(0, 0);
+  __syncthreads();   // (DMA: hipcc drains the LDS-DMA in front of the barrier)
+  // (the stage is a compile-time constant of the tile body -- the loop runs over tile PAIRS -- so that every LDS address is a
+  //  per-lane base + immediate)
+  auto tile = [&](int kt, auto buf_c) {
+    constexpr int buf = decltype(buf_c)::value;
+    if (kt + 1 < n_kt) { gload(kt + 1); dma(kt + 1, buf ^ 1); }
     const bool mask_tile = kt == n_kt - 1 && (T % KB) != 0;   // wave-uniform
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      f32x16 st = c_lse, dpt = c_D;
+      f32x16 st, dpt;
+      if constexpr (CD) {
+        st = c_lse;
+        dpt = c_D;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { st[j] = 0.f; dpt[j] = 0.f; }
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kr(buf) + row_off(32 * g + r, 2 * s + hh));
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kr(buf) + (DMA ? dual_off(32 * g + r, 2 * s + hh) : row_off(32 * g + r, 2 * s + hh)));
         const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vr(buf) + row_off(32 * g + r, 2 * s + hh));
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dpt, 0, 0, 0);
@@ -208,11 +293,11 @@ __global__ __launch_bounds__(256, GWW_ATTBWD_DQ_WAVES) void k_attn_bwd_dq(const 
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
             const int key = kt * KB + 32 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
-            st[j] = (key < T) ? __builtin_amdgcn_exp2f(st[j]) * dpt[j] : 0.f;
+            st[j] = (key < T) ? __builtin_amdgcn_exp2f(CD ? st[j] : st[j] - lse_q) * (CD ? dpt[j] : dpt[j] - D_q) : 0.f;
           }
         } else {
 #pragma unroll
-          for (int j = 0; j < 16; ++j) st[j] = __builtin_amdgcn_exp2f(st[j]) * dpt[j];
+          for (int j = 0; j < 16; ++j) st[j] = __builtin_amdgcn_exp2f(CD ? st[j] : st[j] - lse_q) * (CD ? dpt[j] : dpt[j] - D_q);
         }
       } else {
 #pragma unroll
@@ -227,11 +312,19 @@ __global__ __launch_bounds__(256, GWW_ATTBWD_DQ_WAVES) void k_attn_bwd_dq(const 
         const bf16x8 dsf = cvt8(st, 8 * s);
 #pragma unroll
         for (int n = 0; n < 2; ++n)
-          dqt[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt(buf), 32 * g + 16 * s, n, lane), dsf, dqt[n], 0, 0, 0);
+          dqt[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(DMA ? tr_frag_dual(Kt(buf), 32 * g + 16 * s, n, lane) : tr_frag(Kt(buf), 32 * g + 16 * s, n, lane), dsf, dqt[n], 0, 0, 0);
       }
     }
     if (kt + 1 < n_kt) lstore(buf ^ 1);
     __syncthreads();
+  };
+  {
+    int kt = 0;
+    for (; kt + 1 < n_kt; kt += 2) {
+      tile(kt, std::integral_constant<int, 0>{});
+      tile(kt + 1, std::integral_constant<int, 1>{});
+    }
+    if (kt < n_kt) tile(kt, std::integral_constant<int, 0>{});
   }
   if (q_row < T) {
     unsigned short* orow = dqkv + ((long)b * T + q_row) * rs + h * DH;
