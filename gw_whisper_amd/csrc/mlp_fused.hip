@@ -287,21 +287,27 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
   };
 
   MSTAMP_DECL
-  for (int i = tid; i < F; i += MF_THREADS) {
-    lds_cb[i] = GWW_MF_SCHED ? ln_cb[i] * 0.125f : ln_cb[i];   // SCHED: the fc1 accumulators hold S / 8 (gelu_slice)
-    // (u is only read by round 1's per-value LayerNorm algebra; with NORM the table stays unwritten here, so the final-LN
-    // staging below -- MODE 3 keeps its gain / bias in the same place -- has no second writer in another wave)
-    if (!GWW_MF_NORM) lds_u[i] = ln_u[i];
-  }
-  if (!GWW_MF_NORM && FIN) __syncthreads();
-  if (!LNQ)
-    for (int i = tid; i < MF_D; i += MF_THREADS) lds_b2[i] = XACC ? b2[i] + bo[i] : b2[i];   // XACC: O holds x + ctx W_o^T + fc2, both biases are added when it is read
-  if (OP)
-    for (int i = tid; i < MF_D; i += MF_THREADS) lds_bo[i] = bo[i];
-  if (FIN)   // gain / bias of the encoder's final LayerNorm (q_u / q_cb carry them in this mode), in the unused u table
-    for (int i = tid; i < MF_D; i += MF_THREADS) { lds_u[i] = q_u[i]; lds_u[MF_D + i] = q_cb[i]; }
-  if (QKV && GWW_MF_NORM)   // (a load issued behind the second seam's stores would wait for them: staged here, 6 KB of LDS)
-    for (int i = tid; i < NQ; i += MF_THREADS) lds_qcb[i] = q_cb[i];
+  // the bias tables of the block -> LDS.  XACC: called BEHIND the x / ctx requests (below), so that their round trip -- a
+  // microsecond of L2 latency, plain loads hipcc waits for one by one -- runs under the panel's HBM round trip instead of in
+  // front of it; the first reader (the seam behind the out_proj GEMM) sits behind eighteen tile barriers
+  auto stage_tables = [&]() {
+    for (int i = tid; i < F; i += MF_THREADS) {
+      lds_cb[i] = GWW_MF_SCHED ? ln_cb[i] * 0.125f : ln_cb[i];   // SCHED: the fc1 accumulators hold S / 8 (gelu_slice)
+      // (u is only read by round 1's per-value LayerNorm algebra; with NORM the table stays unwritten here, so the final-LN
+      // staging below -- MODE 3 keeps its gain / bias in the same place -- has no second writer in another wave)
+      if (!GWW_MF_NORM) lds_u[i] = ln_u[i];
+    }
+    if (!GWW_MF_NORM && FIN) __syncthreads();
+    if (!LNQ)
+      for (int i = tid; i < MF_D; i += MF_THREADS) lds_b2[i] = XACC ? b2[i] + bo[i] : b2[i];   // XACC: O holds x + ctx W_o^T + fc2, both biases are added when it is read
+    if (OP)
+      for (int i = tid; i < MF_D; i += MF_THREADS) lds_bo[i] = bo[i];
+    if (FIN)   // gain / bias of the encoder's final LayerNorm (q_u / q_cb carry them in this mode), in the unused u table
+      for (int i = tid; i < MF_D; i += MF_THREADS) { lds_u[i] = q_u[i]; lds_u[MF_D + i] = q_cb[i]; }
+    if (QKV && GWW_MF_NORM)   // (a load issued behind the second seam's stores would wait for them: staged here, 6 KB of LDS)
+      for (int i = tid; i < NQ; i += MF_THREADS) lds_qcb[i] = q_cb[i];
+  };
+  if constexpr (!XACC) stage_tables();
   // De-phase the first round of workgroups (later ones inherit the offsets as CUs free up): panels take
   // the same time everywhere, so without this every CU is in its HBM phase (prologue / epilogue) at the
   // same moment and idles HBM during the MFMA phase.
@@ -344,7 +350,25 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
     const long g = m_base + 8 * i + crow;
     grow[i] = g < M ? g : M - 1;
   }
-  if constexpr (OP) {
+  if constexpr (XACC) {
+    // ---- XACC prologue: the A fragments of the out_proj GEMM come STRAIGHT from global memory -- af[4 S + j] of lane (r, hh)
+    // is ctx[row r][64 S + 32 hh + 8 j .. + 7], 16 contiguous bytes; the four requests j = 0 .. 3 of a k-tile share each row's
+    // 128-byte line through the vector L1 (no nt hint), as the x requests above do.  No staging registers, no LDS transpose
+    // (24 ds_write_b128 + 24 ds_read_b128 per lane and their hand-counted waits in the row-order form below).
+    const unsigned coff = (unsigned)xrow_l * (unsigned)(MF_D * 2) + 64u * (unsigned)hh;
+#pragma unroll
+    for (int S = 0; S < MF_KT; ++S)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(af[4 * S + j]) : "v"(coff), "s"(delta), "n"((64 * S + 8 * j) * 2) : "memory");
+    stage_tables();
+    // one wait for the panel: ring tiles, x, ctx and the tables (loads retire in issue order; hipcc's own waits for the table
+    // values already imply it -- this one is for the reader).  The fences keep the fragments' first use behind it.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MF_KT * 4; ++i) asm volatile("" : "+v"(af[i]));
+    row_rstd = 1.f; row_mean = 0.f;   // set by the seam behind the out_proj GEMM
+  } else if constexpr (OP) {
     // ---- OP prologue: the attention context panel (bf16, read once in whole 128-byte lines: 16 bytes per lane, 8 lanes
     // per row of a 64-column k-tile) goes through the wave-private slice into the A fragments of the out_proj GEMM.  All
     // 24 loads of a lane in flight at once (asm + counted waits, as below): load k is complete once 23 - k younger ones
