@@ -547,12 +547,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void k_attention_l2_bf16(
 // straight away and their row sum (needed anyway) is the overflow detector: any p above 2^kDefer -- or an inf -- makes
 // the sum exceed the trigger; only then (rare, wave-uniform) the scores are recomputed from the K tile still in LDS,
 // the exact row maximum is taken and O, l and the reference are re-based.  23 v_max per tile leave the hot path.
+#ifndef GWW_ATT_NBUF
+#define GWW_ATT_NBUF 2   // K / V buffers of k_attention_dma_bf16.  3 (round 4 experiment, tools/attfwd_exp.py NBUF=2 NBUF=3): the
+                         // LDS-DMA of tile kt + 2 issued at the top of tile kt behind counted waits -- correct, 4 % SLOWER (1.073 /
+                         // 1.084 against 1.031 / 1.042 ms on one box): the K / V pieces are L2 hits that land within a tile time
+#endif
 template <int MINW, bool MSUM, bool NOMAX>
 __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned short* __restrict__ qkv,
                                                                  unsigned short* __restrict__ ctx,
                                                                  float* __restrict__ lse, int T, int H, int q_tiles,
                                                                  int qt0) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KB * DH * 2];   // K0 | K1 | V0 | V1, 8 KB each
+  // NB = 3 (round 4 experiment, off): THREE K / V buffers, the LDS-DMA of tile kt + 2 issued at the top of tile kt and only tile
+  // kt + 1's pieces awaited at its end (asm DMA + counted vmcnt: hipcc's __syncthreads() drains every LDS-DMA in flight) -- a
+  // tile's pieces get two tile times to arrive instead of one.  48 KB per workgroup: three workgroups still fit a CU.
+  constexpr int NB = GWW_ATT_NBUF;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NB * 2 * KB * DH * 2];   // K0 .. | V0 .., 8 KB each
   constexpr int TILE_BYTES = KB * DH * 2, NW = 4;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* g_ptr;
@@ -593,8 +602,32 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
     const char* kb = reinterpret_cast<const char*>(kp + (long)kt * KB * row_stride);   // wave-uniform
     const char* vb = reinterpret_cast<const char*>(vp + (long)kt * KB * row_stride);
     unsigned char* dk = lds + BUF * TILE_BYTES + (2 * wave_u) * 1024;
-    unsigned char* dv = dk + 2 * TILE_BYTES;
-    if (kt != n_kt - 1 || !ragged) {
+    unsigned char* dv = dk + NB * TILE_BYTES;
+    if constexpr (NB == 3) {
+      // one M0 (wave-uniform LDS destination) and one SGPR base per image; the piece enters as the instruction's immediate,
+      // which the hardware adds to the LDS address -- its global side is folded into the per-lane offset
+      const unsigned mk = (unsigned)(unsigned long long)(lds_ptr)dk, mv = (unsigned)(unsigned long long)(lds_ptr)dv;
+      unsigned ko[2], vo[2];
+      if (kt != n_kt - 1 || !ragged) {
+        ko[0] = koff[0]; ko[1] = koff[1]; vo[0] = voff[0]; vo[1] = voff[1];
+      } else {   // ragged last tile: rows past T - 1 read row T - 1
+        const int last_row = T - 1 - kt * KB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = 8 * (2 * wave + j) + (lane >> 3), pos = lane & 7;
+          const int rc = row < last_row ? row : last_row;
+          ko[j] = (unsigned)(rc * (int)row_stride * 2 + ((pos ^ ((row >> 1) & 7)) << 4));
+          vo[j] = (unsigned)(rc * (int)row_stride * 2 + ((pos ^ (((row >> 1) & 1) << 2)) << 4));
+        }
+      }
+      // (one M0 per piece: an instruction immediate would be added to the GLOBAL address too, and a clamped row of the ragged
+      //  tile has no 1 KiB to give back -- the first version of this path wrapped its offset below zero and faulted on T = 1)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(ko[j]), "s"(kb), "s"(mk + 1024u * j) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo[j]), "s"(vb), "s"(mv + 1024u * j) : "memory");
+      }
+    } else if (kt != n_kt - 1 || !ragged) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         __builtin_amdgcn_global_load_lds((g_ptr)(kb + koff[j]), (lds_ptr)(dk + j * 1024), 16, 0, 0);
@@ -621,7 +654,7 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
   for (int s = 0; s < 4; ++s) kbase[s] = lds + k_off(r, 2 * s + hh);
   const unsigned char* vbase[2];
 #pragma unroll
-  for (int n = 0; n < 2; ++n) vbase[n] = lds + 2 * TILE_BYTES + v_off(4 * hh + tr_q, 64 * n + tr_colbyte);
+  for (int n = 0; n < 2; ++n) vbase[n] = lds + NB * TILE_BYTES + v_off(4 * hh + tr_q, 64 * n + tr_colbyte);
 
   f32x16 ot[2], lt;
 #pragma unroll
@@ -633,10 +666,13 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
   constexpr float kDeferL2 = 8.0f * kLog2e;
   typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
 
-  auto tile = [&](int kt, auto buf_c, auto first_c, auto masked_c) {
+  auto tile = [&](int kt, auto buf_c, auto first_c, auto masked_c, bool masked_rt = false) {
     constexpr int BUF = decltype(buf_c)::value;
-    constexpr bool FIRST = decltype(first_c)::value, MASKED = decltype(masked_c)::value;
-    if (kt + 1 < n_kt) dma(kt + 1, std::integral_constant<int, BUF ^ 1>{});
+    constexpr bool FIRST = decltype(first_c)::value;
+    // (NB = 3: the ragged-tile flag is a wave-uniform RUNTIME value -- the steady loop then holds three tile bodies and nothing
+    //  else; as a template flag the remainder paths added six more copies and 162 spilled registers around them)
+    const bool MASKED = NB == 3 ? masked_rt : decltype(masked_c)::value;
+    if (kt + NB - 1 < n_kt) dma(kt + NB - 1, std::integral_constant<int, (BUF + NB - 1) % NB>{});
     // Work that cannot contribute is skipped (wave-uniform tests; T = 1500: 2 % + 2 % of the launch): a wave whose 32 query
     // rows all lie past T - 1 (the last query tile's tail) only requests its pieces and joins the barrier; the ragged last
     // key tile computes its second key half only if a valid key lies in it (1500 = 23 x 64 + 28: it does not)
@@ -662,7 +698,7 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
           st[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[g], 0, 0, 0);
         }
       }
-      if constexpr (MASKED) {
+      if (MASKED) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -749,32 +785,59 @@ __global__ __launch_bounds__(256, MINW) void k_attention_dma_bf16(const unsigned
       }
     }
     }   // wave_live
-    __syncthreads();   // vmcnt(0): this wave's pieces of tile kt + 1 have landed; barrier: everybody's have
+    if constexpr (NB == 3) {   // tile kt + 1's four pieces have landed; tile kt + 2's (issued at this tile's top) may stay in flight
+      if (kt + 2 < n_kt) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      __syncthreads();   // vmcnt(0): this wave's pieces of tile kt + 1 have landed; barrier: everybody's have
+    }
   };
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
   using Yes = std::true_type;
   using No = std::false_type;
 
-  dma(0, P0{});
-  __syncthreads();
-  if (n_kt == 1) {
-    if (ragged) tile(0, P0{}, Yes{}, Yes{});
-    else tile(0, P0{}, Yes{}, No{});
-  } else {
-    tile(0, P0{}, Yes{}, No{});
-    int kt = 1;
-    for (; kt + 2 <= n_kt - 1; kt += 2) {
-      tile(kt, P1{}, No{}, No{});
-      tile(kt + 1, P0{}, No{}, No{});
-    }
-    if (kt == n_kt - 2) {
-      tile(kt, P1{}, No{}, No{});
-      if (ragged) tile(kt + 1, P0{}, No{}, Yes{});
-      else tile(kt + 1, P0{}, No{}, No{});
+  if constexpr (NB == 3) {
+    using P2 = std::integral_constant<int, 2>;
+    dma(0, P0{});
+    if (n_kt > 1) {
+      dma(1, P1{});
+      asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
     } else {
-      if (ragged) tile(kt, P1{}, No{}, Yes{});
-      else tile(kt, P1{}, No{}, No{});
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // (touch the Q fragments here: hipcc then waits for their loads in front of the loop; left pending into the loop header,
+    //  its counter model re-waits for them in every tile with counts that also drain the K / V requests in flight)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) asm volatile("" : "+v"(qf[s4]));
+    tile(0, P0{}, Yes{}, No{}, n_kt == 1 && ragged);
+    // steady state: buffers 1, 2, 0, 1, ... (compile-time in every tile body; the guards are scalar branches)
+    for (int kt = 1; kt < n_kt; kt += 3) {
+      tile(kt, P1{}, No{}, No{}, ragged && kt == n_kt - 1);
+      if (kt + 1 < n_kt) tile(kt + 1, P2{}, No{}, No{}, ragged && kt + 1 == n_kt - 1);
+      if (kt + 2 < n_kt) tile(kt + 2, P0{}, No{}, No{}, ragged && kt + 2 == n_kt - 1);
+    }
+  } else {
+    dma(0, P0{});
+    __syncthreads();
+    if (n_kt == 1) {
+      if (ragged) tile(0, P0{}, Yes{}, Yes{});
+      else tile(0, P0{}, Yes{}, No{});
+    } else {
+      tile(0, P0{}, Yes{}, No{});
+      int kt = 1;
+      for (; kt + 2 <= n_kt - 1; kt += 2) {
+        tile(kt, P1{}, No{}, No{});
+        tile(kt + 1, P0{}, No{}, No{});
+      }
+      if (kt == n_kt - 2) {
+        tile(kt, P1{}, No{}, No{});
+        if (ragged) tile(kt + 1, P0{}, No{}, Yes{});
+        else tile(kt + 1, P0{}, No{}, No{});
+      } else {
+        if (ragged) tile(kt, P1{}, No{}, Yes{});
+        else tile(kt, P1{}, No{}, No{});
+      }
     }
   }
 
