@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import ctypes as C
 import sys
+import weakref
 from dataclasses import dataclass
 
 import torch
@@ -57,7 +58,39 @@ class BaseModelOutput:
         return (self.last_hidden_state,)[i]
 
 
-class _Attention(nn.Module):
+# Structure epoch: bumped whenever a sub-module or parameter is (re)assigned on one of the encoder's own module classes -- which is
+# how adapters get attached (peft's / the shim's ``setattr(parent, leaf, wrapper)``).  The per-step host work of a training
+# forward used to walk the module tree five times (``parameters()`` / ``named_parameters()`` are recursive generators: ~0.3 ms
+# per step with the GPU idle behind the loop's per-step sync); the parameter lists are now cached per epoch and only the cheap
+# per-parameter fields (requires_grad, data_ptr, _version) are read fresh.
+_EPOCH = [0]
+
+
+class _Tracked(nn.Module):
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Module, nn.Parameter)) or name in self.__dict__.get("_modules", ()) \
+                or name in self.__dict__.get("_parameters", ()):
+            _EPOCH[0] += 1
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        _EPOCH[0] += 1
+        super().__delattr__(name)
+
+    def add_module(self, name, module):
+        _EPOCH[0] += 1
+        super().add_module(name, module)
+
+    def register_module(self, name, module):
+        _EPOCH[0] += 1
+        super().register_module(name, module)
+
+    def register_parameter(self, name, param):
+        _EPOCH[0] += 1
+        super().register_parameter(name, param)
+
+
+class _Attention(_Tracked):
     def __init__(self, d):
         super().__init__()
         self.k_proj = nn.Linear(d, d, bias=False)
@@ -66,7 +99,7 @@ class _Attention(nn.Module):
         self.out_proj = nn.Linear(d, d, bias=True)
 
 
-class _EncoderLayer(nn.Module):
+class _EncoderLayer(_Tracked):
     def __init__(self, d, ffn):
         super().__init__()
         self.self_attn = _Attention(d)
@@ -74,6 +107,39 @@ class _EncoderLayer(nn.Module):
         self.fc1 = nn.Linear(d, ffn)
         self.fc2 = nn.Linear(ffn, d)
         self.final_layer_norm = nn.LayerNorm(d)
+
+
+# Encoders that have run a training forward.  An optimizer step changes their adapters, and the next forward would start by
+# re-preparing the packed weights (DoRA merge, panel packs, LayerNorm folds: host work + a handful of launches) with the GPU
+# idle behind the step's loss.item() / synchronize -- the reference loop syncs every step (Signal_vs_Noise/src/train.py:163-168).
+# A global optimizer post-step hook does that work right behind optimizer.step(), while the GPU is still busy with the step's
+# backward: the next forward finds its change keys equal and returns at once.  Nothing is assumed about the caller's loop: a
+# weight changed later (load_state_dict, another optimizer) changes the keys again and is re-synced as before.
+_TRAINED = weakref.WeakSet()
+_HOOKED = False
+
+
+def _post_step_sync(*_args, **_kw):
+    for enc in list(_TRAINED):
+        try:
+            if enc._handle is None or not enc._has_trainable_adapters():
+                continue
+            dev = enc._param_cache()[1][0][1].device
+            if dev.type != "cuda":
+                continue
+            with torch.no_grad(), torch.cuda.device(dev):
+                enc._sync_weights()
+        except Exception:
+            pass   # (a failed early sync is not an error: the next forward syncs and reports)
+
+
+def _note_training(enc):
+    global _HOOKED
+    _TRAINED.add(enc)
+    if not _HOOKED:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        register_optimizer_step_post_hook(_post_step_sync)
+        _HOOKED = True
 
 
 def _effective_weight(linear) -> torch.Tensor:
@@ -88,7 +154,7 @@ def _bias(linear):
     return base.bias
 
 
-class WhisperEncoder(nn.Module):
+class WhisperEncoder(_Tracked):
     """Parameter container + launcher for the HIP encoder forward."""
 
     def __init__(self, config: WhisperConfig, precision: str = "bf16"):
@@ -149,21 +215,28 @@ class WhisperEncoder(nn.Module):
             self._handle = h
         return self._handle
 
-    @staticmethod
-    def _mod_key(*mods):
-        """(data_ptr, version) of every parameter under the given modules (DoRA wrappers included)."""
-        return tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
-
-    def _group_keys(self):
-        """Change keys per weight group: globals, and per layer the four groups of gww_encoder_update_weights
-        (bit 0 q/k/v + LN1, bit 1 out_proj, bit 2 fc1 + LN2, bit 3 fc2)."""
-        g = self._mod_key(self.conv1, self.conv2, self.embed_positions, self.layer_norm)
-        layers = []
+    def _param_cache(self):
+        """(all (name, parameter) pairs, parameter lists per weight group) -- rebuilt when the module structure changed."""
+        c = self.__dict__.get("_pcache")
+        if c is not None and c[0] == _EPOCH[0]:
+            return c
+        plist = lambda *mods: [p for m in mods for p in m.parameters()]
+        groups = [plist(self.conv1, self.conv2, self.embed_positions, self.layer_norm)]
         for L in self.layers:
             a = L.self_attn
-            layers.append((self._mod_key(a.q_proj, a.k_proj, a.v_proj, L.self_attn_layer_norm),
-                           self._mod_key(a.out_proj), self._mod_key(L.fc1, L.final_layer_norm), self._mod_key(L.fc2)))
-        return g, layers
+            groups.append((plist(a.q_proj, a.k_proj, a.v_proj, L.self_attn_layer_norm), plist(a.out_proj),
+                           plist(L.fc1, L.final_layer_norm), plist(L.fc2)))
+        c = (_EPOCH[0], list(self.named_parameters()), groups)
+        self.__dict__["_pcache"] = c
+        return c
+
+    def _group_keys(self):
+        """Change keys per weight group -- (data_ptr, version) of every parameter of the group, DoRA wrappers included:
+        globals, and per layer the four groups of gww_encoder_update_weights (bit 0 q/k/v + LN1, bit 1 out_proj, bit 2 fc1 + LN2,
+        bit 3 fc2)."""
+        groups = self._param_cache()[2]
+        key = lambda ps: tuple((p.data_ptr(), p._version) for p in ps)
+        return key(groups[0]), [tuple(key(ps) for ps in g) for g in groups[1:]]
 
     def _sync_weights(self):
         """Re-pack into the library's bf16/fp32 panels what changed since the last call (optimizer step,
@@ -293,9 +366,10 @@ class WhisperEncoder(nn.Module):
         # Only the frozen-base + DoRA backward exists (and the input gradient).  A base parameter that was un-frozen on
         # purpose -- the reference's `full_finetune` method, Signal_vs_Noise/src/train.py:244-250 -- would silently get no
         # gradient: refuse.  (Cheap path first: nothing trainable at all is the inference case.)
-        if not any(p.requires_grad for p in self.parameters()):
+        named = self._param_cache()[1]
+        if not any(p.requires_grad for _, p in named):
             return torch.is_tensor(input_features) and input_features.requires_grad
-        base_trainable = [n for n, p in self.named_parameters() if p.requires_grad and "lora_" not in n]
+        base_trainable = [n for n, p in named if p.requires_grad and "lora_" not in n]
         if base_trainable:
             raise _lib.GwwError(
                 "WhisperEncoder: autograd is on and base parameters require grad (e.g. " + base_trainable[0] + "): only "

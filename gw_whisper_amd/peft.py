@@ -109,6 +109,8 @@ class DoraLinear(nn.Module):
         if use_dora:
             with torch.no_grad():   # m = ||W0 + s B A||_row with B = 0 -> identity at init
                 self.lora_magnitude_vector[adapter] = _Magnitude(torch.linalg.norm(base.weight.detach(), dim=1))
+        from . import encoder as _enc   # (a wrapper that reaches an encoder by any route invalidates its cached parameter lists)
+        _enc._EPOCH[0] += 1
 
     # what peft exposes on the wrapper
     @property

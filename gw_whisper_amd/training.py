@@ -19,6 +19,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from . import encoder as _encoder
 from ._lib import check, lib
 from .peft import DoraLinear
 
@@ -46,6 +47,7 @@ class _EncoderTrain(torch.autograd.Function):
         dev = x.device
         with torch.cuda.device(dev):
             enc._sync_weights()
+            _encoder._note_training(enc)   # from now on the packed weights follow every optimizer step at once
             h = enc._ensure_handle()
             ws = torch.empty((lib().gww_train_workspace_bytes(h, B),), dtype=torch.uint8, device=dev)
             saved = torch.empty((lib().gww_train_saved_bytes(h, B),), dtype=torch.uint8, device=dev)

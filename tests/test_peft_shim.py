@@ -160,3 +160,38 @@ def test_datasets_directory_round_trip_through_the_harness_loader(tmp_path):
         got = rt.load_arrays(types.SimpleNamespace(synthetic=0, data_path=str(tmp_path / path)))
         for g, k in zip(got, ("h1_timeseries", "l1_timeseries", "labels", "injection_snr")):
             assert g.dtype == np.float32 and np.array_equal(g, cols[k]), (path, k)
+
+
+def test_cached_parameter_lists_follow_the_module_structure():
+    """The encoder caches its parameter lists per structure epoch (encoder._EPOCH: the per-step host work of a training forward
+    used to walk the module tree five times).  Attaching adapters, replacing a sub-module or re-assigning a parameter must
+    invalidate the cache; requires_grad, data_ptr and _version are always read fresh."""
+    from gw_whisper_amd import encoder as E, _lib
+    enc = WhisperEncoder(WhisperConfig(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256))
+    named0 = enc._param_cache()[1]
+    assert [n for n, _ in named0] == [n for n, _ in enc.named_parameters()]
+    assert enc._param_cache() is enc._param_cache()                    # cached while nothing changes
+    g0, l0 = enc._group_keys()
+    with torch.no_grad():
+        enc.layers[1].fc1.weight.add_(1.0)                              # an in-place update bumps _version: key of group 2 only
+    g1, l1 = enc._group_keys()
+    assert g1 == g0 and l1[0] == l0[0] and l1[1][2] != l0[1][2] and l1[1][0] == l0[1][0]
+    targets = _targets(enc, ["layers.*.self_attn.q_proj", "layers.*.self_attn.v_proj"])
+    peft = get_peft_model(enc, LoraConfig(use_dora=True, r=4, lora_alpha=8, target_modules=targets))
+    names = [n for n, _ in enc._param_cache()[1]]
+    assert names == [n for n, _ in enc.named_parameters()] and any("lora_A" in n for n in names)
+    assert len(enc._group_keys()[1][0][0]) > len(l0[0][0])              # the wrappers' parameters joined the q/k/v group
+    for n, p in peft.named_parameters():
+        p.requires_grad = "lora" in n
+    x = torch.zeros(1, 80, 3000)
+    assert enc._wants_grad(x) and enc._has_trainable_adapters()
+    with torch.no_grad():
+        assert not enc._wants_grad(x)
+    enc.layers[0].fc2.weight.requires_grad = True                       # a base weight un-frozen on purpose: refused, read fresh
+    with pytest.raises(_lib.GwwError):
+        enc._wants_grad(x)
+    enc.layers[0].fc2.weight.requires_grad = False
+    e = E._EPOCH[0]
+    enc.layers[0].fc2 = torch.nn.Linear(256, 128)                       # a replaced sub-module: new epoch, new lists
+    assert E._EPOCH[0] > e and enc._param_cache()[1][0][1] is not None
+    assert any(p is enc.layers[0].fc2.weight for _, p in enc._param_cache()[1])
