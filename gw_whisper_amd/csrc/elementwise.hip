@@ -65,12 +65,73 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
   }
 }
 
+// The same for d % 256 == 0 (whisper-base / -small: 24 launches per whisper-small forward, 8-9 % of it) with 16 bytes per lane on
+// the read side and 8 / 16 on the write side: N4 = d / 256 float4 per lane.
+template <int N4, bool OUT_BF16>
+__global__ __launch_bounds__(256) void k_layernorm4(const float* __restrict__ x, long row_stride,
+                                                    const unsigned short* __restrict__ delta,
+                                                    const float* __restrict__ w, const float* __restrict__ b,
+                                                    void* __restrict__ y, long M) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  constexpr int d = N4 * 256;
+  const float4* xr = reinterpret_cast<const float4*>(x + row * row_stride);
+  float4 v[N4];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < N4; ++j) {
+    v[j] = xr[lane + 64 * j];
+    if (delta) {
+      const u32x2 dv = reinterpret_cast<const u32x2*>(delta + row * row_stride)[lane + 64 * j];
+      v[j].x += bf2f((unsigned short)(dv[0] & 0xffff)); v[j].y += bf2f((unsigned short)(dv[0] >> 16));
+      v[j].z += bf2f((unsigned short)(dv[1] & 0xffff)); v[j].w += bf2f((unsigned short)(dv[1] >> 16));
+    }
+    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+  const float mean = wave_sum(s) * (1.0f / d);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < N4; ++j) {
+    v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+    q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / d) + 1e-5f);
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+#pragma unroll
+  for (int j = 0; j < N4; ++j) {
+    const float4 ww = w4[lane + 64 * j], bb = b4[lane + 64 * j];
+    const float o0 = v[j].x * rstd * ww.x + bb.x, o1 = v[j].y * rstd * ww.y + bb.y;
+    const float o2 = v[j].z * rstd * ww.z + bb.z, o3 = v[j].w * rstd * ww.w + bb.w;
+    if (OUT_BF16) {
+      reinterpret_cast<u32x2*>(y)[row * (d / 4) + lane + 64 * j] = u32x2{pack2bf(o0, o1), pack2bf(o2, o3)};
+    } else {
+      reinterpret_cast<float4*>(y)[row * (d / 4) + lane + 64 * j] = make_float4(o0, o1, o2, o3);
+    }
+  }
+}
+
 template <bool OUT_BF16>
 static int ln_dispatch(const float* x, long row_stride, const unsigned short* delta, const float* w,
                        const float* b, void* y, long M, int d, hipStream_t s) {
   GWW_REQUIRE(d % 128 == 0 && d >= 128 && d <= 1280, "layernorm: d=%d must be a multiple of 128 <= 1280", d);
   if (M == 0) return GWW_OK;
   dim3 grid((unsigned)cdiv(M, 4)), block(256);
+  // (same arithmetic in the same order per ELEMENT; the row sums group four elements instead of two: last-bit differences of
+  //  mean / rstd are possible between the two forms, each is deterministic)
+  if (d % 256 == 0 && row_stride % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0 &&
+      (!delta || (((uintptr_t)delta) & 7) == 0)) {
+    switch (d / 256) {
+      case 1: hipLaunchKernelGGL((k_layernorm4<1, OUT_BF16>), grid, block, 0, s, x, row_stride, delta, w, b, y, M); break;
+      case 2: hipLaunchKernelGGL((k_layernorm4<2, OUT_BF16>), grid, block, 0, s, x, row_stride, delta, w, b, y, M); break;
+      case 3: hipLaunchKernelGGL((k_layernorm4<3, OUT_BF16>), grid, block, 0, s, x, row_stride, delta, w, b, y, M); break;
+      case 4: hipLaunchKernelGGL((k_layernorm4<4, OUT_BF16>), grid, block, 0, s, x, row_stride, delta, w, b, y, M); break;
+      default: hipLaunchKernelGGL((k_layernorm4<5, OUT_BF16>), grid, block, 0, s, x, row_stride, delta, w, b, y, M); break;
+    }
+    GWW_LAUNCH_CHECK();
+    return GWW_OK;
+  }
 #define GWW_LN_CASE(NV)                                                                          \
   case NV:                                                                                       \
     hipLaunchKernelGGL((k_layernorm<NV, OUT_BF16>), grid, block, 0, s, x, row_stride, delta, w, b, y, M); \
