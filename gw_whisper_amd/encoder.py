@@ -245,6 +245,11 @@ class WhisperEncoder(_Tracked):
         gkey, lkeys = self._group_keys()
         old = self._packed_key
         if old is not None and old == (gkey, lkeys):
+            # The panels may have been packed on ANOTHER stream (the optimizer post-step hook runs on whatever stream
+            # optimizer.step() ran on): order this stream behind that work once.
+            ev = self.__dict__.get("_packed_event")
+            if ev is not None and ev[0] != torch.cuda.current_stream().cuda_stream:
+                torch.cuda.current_stream().wait_event(ev[1])
             return
         full = old is None
         g_dirty = full or old[0] != gkey
@@ -298,6 +303,9 @@ class WhisperEncoder(_Tracked):
             check(lib().gww_encoder_update_weights(self._ensure_handle(), C.byref(g) if g is not None else None, arr, n,
                                                    dirty, stream), "gww_encoder_update_weights")
         self._packed_key = (gkey, lkeys)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.__dict__["_packed_event"] = (stream, ev)
 
     def _workspace(self, batch: int, prec: int, device) -> torch.Tensor:
         need = lib().gww_encoder_workspace_bytes(self._ensure_handle(), batch, prec)
