@@ -72,6 +72,18 @@ constexpr int MF_WAVES = 4, MF_THREADS = 256, MF_BM = 128;
 #else
 #define MF_NT ""
 #endif
+#ifndef GWW_MF_PADNOP
+#define GWW_MF_PADNOP 0   // 1: two wait states in front of the asm MFMAs of the out_proj GEMM and the q / k / v tail (hipcc may place
+                          // a register copy directly in front of an MFMA it cannot see inside an asm statement) -- rounds 2 / 3.
+                          // 0 (round 4): without them; build() runs tools/audit_asm_mfma.py over the ISA of every instantiation
+                          // and fails on the first MFMA with an operand written too close in front of it.  1 152 s_nop per wave:
+                          // 1.430 / 1.428 -> 1.407 / 1.414 ms for <1, true> (tools/mlp_exp2.py PADNOP=1 PADNOP=0, twice each)
+#endif
+#if GWW_MF_PADNOP
+#define MF_PADNOP "s_nop 1\n\t"
+#else
+#define MF_PADNOP ""
+#endif
 #ifndef GWW_MF_XLDS
 #define GWW_MF_XLDS 0   // 1: XACC's x_next / x_new / y leave through the wave-private LDS slices in ROW order (whole 128-byte lines, 8
                         // rows per store instruction) instead of from the accumulator layout (32-byte row pieces per lane pair).
@@ -1056,7 +1068,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
           if (!(GWW_MF_ABL & 128)) issue_piece(dma_tile, dma_st, sub);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(oacc[4 * nt + u]) : "v"(cur[u]), "v"(af[4 * kt + sub]));
+            asm volatile(MF_PADNOP "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(oacc[4 * nt + u]) : "v"(cur[u]), "v"(af[4 * kt + sub]));
             const int off = (last && sub == 3) ? (u & 1) * 8192 + off1[u >> 1] : u * 4096 + offq[(sub + 1) & 3];
             nxt[u] = *reinterpret_cast<const bf16x8*>(Wn + off);
           }
@@ -1552,7 +1564,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void k_mlp_fused(const float* X, con
             // accumulators in architectural registers, preloaded with the folded bias (below): the n-tile epilogue is a
             // pack + store, no v_accvgpr_read_b32 (8 cycles each in the open), no bias read / add per value.  asm: see
             // the main loop; two wait states in front cover register copies hipcc may place there (ISA audit in build())
-            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(cur[u]), "v"(af[4 * kt + sub]));
+            asm volatile(MF_PADNOP "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(cur[u]), "v"(af[4 * kt + sub]));
 #else
             if (kt == 0 && sub == 0) {
               f32x16 z;
