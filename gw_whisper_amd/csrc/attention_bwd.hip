@@ -24,9 +24,10 @@ constexpr int DH = 64, TB = 128, KB = 64;
 #ifndef GWW_ATTBWD_DMA
 #define GWW_ATTBWD_DMA 1   // round 4: k_attn_bwd_dq stages K / V by LDS-DMA (no staging registers, no ds_write_b128) and keeps ONE
                            // image of K that serves the row reads of S = K Q^T and the transposed reads of dQ = dS K (dual_off
-                           // below): 32 KB of LDS.  Measured (tools/attbwd_exp.py, rowdot + dq + dkv at B = 64): 1.114 -> 1.078 ms
-                           // at two workgroups per CU; three per CU (168 registers: the accumulator start values have to go and 15
-                           // registers still spill) 1.086 -- not kept
+                           // below): 32 KB of LDS; k_attn_bwd_dkv likewise for Q and dO (237 -> 171 registers, 65 -> 33 KB).
+                           // Measured (tools/attbwd_exp.py, rowdot + dq + dkv at B = 64, bit-identical results): 1.051 -> 1.028-1.034 ms;
+                           // dq at three workgroups per CU (168 registers: the accumulator start values have to go and 15 registers
+                           // still spill) was slower -- not kept
 #endif
 #ifndef GWW_ATTBWD_DQ_WAVES
 #define GWW_ATTBWD_DQ_WAVES 2   // workgroups per CU of k_attn_bwd_dq
@@ -341,8 +342,12 @@ __global__ __launch_bounds__(256, GWW_ATTBWD_DQ_WAVES) void k_attn_bwd_dq(const 
 // ------------------------------------------------------------------------------------ dK, dV
 // L2Q: -lse log2(e) and -D of the tile's 64 queries are staged NEGATED and read from LDS straight into the accumulators of
 // S and dP (the query rows sit in the registers here); dS = p dP' without its 1 / log2(e), which the finished dK gets once.
+#ifndef GWW_ATTBWD_DKV_WAVES
+#define GWW_ATTBWD_DKV_WAVES 2   // workgroups per CU of k_attn_bwd_dkv (DMA form: 171 registers, 33 KB of LDS; 3 per CU = 168 registers, 6 spilled:
+                                 // 1.021 against 1.028 - 1.034 ms for rowdot + dq + dkv, tools/attbwd_exp.py -- not kept)
+#endif
 template <bool L2Q>
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* __restrict__ qkv,
+__global__ __launch_bounds__(256, GWW_ATTBWD_DKV_WAVES) void k_attn_bwd_dkv(const unsigned short* __restrict__ qkv,
                                                          const unsigned short* __restrict__ dctx,
                                                          const float* __restrict__ lse,
                                                          const float* __restrict__ Dv,
@@ -350,13 +355,19 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
                                                          int k_tiles, const unsigned int* __restrict__ nz,
                                                          float ssc, float gsc) {
   // per stage: Q row image, Q transposed-read image, dO row image, dO transposed-read image, lse[64], D[64]
-  constexpr int STAGE = 4 * TILE_BYTES + 512;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];   // 65 KB
+  // (DMA, round 4: ONE dual-use image each for Q and dO -- dual_off above -- staged by LDS-DMA: 33 instead of 65 KB, no staging
+  //  registers, no ds_write_b128)
+  constexpr bool DMA = GWW_ATTBWD_DMA != 0;
+  constexpr int IMG = DMA ? 2 : 4;
+  constexpr int STAGE = IMG * TILE_BYTES + 512;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
   auto Qr = [&](int buf) -> unsigned char* { return lds + buf * STAGE; };
-  auto Qt = [&](int buf) -> unsigned char* { return lds + buf * STAGE + TILE_BYTES; };
-  auto Or = [&](int buf) -> unsigned char* { return lds + buf * STAGE + 2 * TILE_BYTES; };
-  auto Ot = [&](int buf) -> unsigned char* { return lds + buf * STAGE + 3 * TILE_BYTES; };
-  auto Ls = [&](int buf) -> float* { return reinterpret_cast<float*>(lds + buf * STAGE + 4 * TILE_BYTES); };
+  auto Qt = [&](int buf) -> unsigned char* { return lds + buf * STAGE + (DMA ? 0 : TILE_BYTES); };
+  auto Or = [&](int buf) -> unsigned char* { return lds + buf * STAGE + (DMA ? 1 : 2) * TILE_BYTES; };
+  auto Ot = [&](int buf) -> unsigned char* { return lds + buf * STAGE + (DMA ? 1 : 3) * TILE_BYTES; };
+  auto Ls = [&](int buf) -> float* { return reinterpret_cast<float*>(lds + buf * STAGE + IMG * TILE_BYTES); };
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* g_ptr;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned nblk = gridDim.x, per = nblk >> 3;   // XCD-aware order: the key tiles of one (b, h) stream the same Q / dO
@@ -392,12 +403,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
   u32x4 rq[2], ro[2];
   float rl = 0.f;
   auto gload = [&](int qt) {
+    if constexpr (!DMA) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int q = qt * KB + st_row[i];
-      if (q >= T) q = T - 1;
-      rq[i] = *reinterpret_cast<const u32x4*>(qp + (long)q * rs + st_chunk[i] * 8);
-      ro[i] = *reinterpret_cast<const u32x4*>(dop + (long)q * d + st_chunk[i] * 8);
+      for (int i = 0; i < 2; ++i) {
+        int q = qt * KB + st_row[i];
+        if (q >= T) q = T - 1;
+        rq[i] = *reinterpret_cast<const u32x4*>(qp + (long)q * rs + st_chunk[i] * 8);
+        ro[i] = *reinterpret_cast<const u32x4*>(dop + (long)q * d + st_chunk[i] * 8);
+      }
     }
     if (tid < 128) {
       const int q = qt * KB + (tid & 63);
@@ -406,13 +419,30 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
       if constexpr (L2Q) rl = -rl;
     }
   };
-  auto lstore = [&](int buf) {
+  // DMA: piece j of wave w = tile rows 8 (2 w + j) .. + 7, 16 bytes per lane; the dual-use swizzle on the per-lane SOURCE chunk;
+  // queries past T - 1 read row T - 1 (their P is 0: lse = +inf)
+  auto dma = [&](int qt, int buf) {
+    if constexpr (DMA) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<u32x4*>(Qr(buf) + row_off(st_row[i], st_chunk[i])) = rq[i];
-      *reinterpret_cast<u32x4*>(Qt(buf) + tr_off(st_row[i], st_chunk[i] * 16)) = rq[i];
-      *reinterpret_cast<u32x4*>(Or(buf) + row_off(st_row[i], st_chunk[i])) = ro[i];
-      *reinterpret_cast<u32x4*>(Ot(buf) + tr_off(st_row[i], st_chunk[i] * 16)) = ro[i];
+      for (int j = 0; j < 2; ++j) {
+        const int row = 8 * (2 * wave + j) + (lane >> 3), pos = lane & 7;
+        int q = qt * KB + row;
+        if (q >= T) q = T - 1;
+        const int ch = (pos ^ dual_x(row)) << 3;
+        __builtin_amdgcn_global_load_lds((g_ptr)(qp + (long)q * rs + ch), (lds_ptr)(Qr(buf) + (2 * wave + j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((g_ptr)(dop + (long)q * d + ch), (lds_ptr)(Or(buf) + (2 * wave + j) * 1024), 16, 0, 0);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    if constexpr (!DMA) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        *reinterpret_cast<u32x4*>(Qr(buf) + row_off(st_row[i], st_chunk[i])) = rq[i];
+        *reinterpret_cast<u32x4*>(Qt(buf) + tr_off(st_row[i], st_chunk[i] * 16)) = rq[i];
+        *reinterpret_cast<u32x4*>(Or(buf) + row_off(st_row[i], st_chunk[i])) = ro[i];
+        *reinterpret_cast<u32x4*>(Ot(buf) + tr_off(st_row[i], st_chunk[i] * 16)) = ro[i];
+      }
     }
     if (tid < 128) Ls(buf)[tid] = rl;   // [0,64): lse * log2e, [64,128): D
   };
@@ -433,12 +463,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
   int qt = next_live(0), buf = 0;
   if (qt < n_qt) {
     gload(qt);
+    dma(qt, 0);
     lstore(0);
   }
-  __syncthreads();
+  __syncthreads();   // (DMA: hipcc drains the LDS-DMA in front of the barrier)
   while (qt < n_qt) {
     const int qn = next_live(qt + 1);
-    if (qn < n_qt) gload(qn);
+    if (qn < n_qt) { gload(qn); dma(qn, buf ^ 1); }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       // S[q][key], dP[q][key]: rows q = 32 g + (reg&3) + 8 (reg>>2) + 4 hh in registers, key on the lane
@@ -457,8 +488,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qr(buf) + row_off(32 * g + r, 2 * s + hh));
-        const bf16x8 oa = *reinterpret_cast<const bf16x8*>(Or(buf) + row_off(32 * g + r, 2 * s + hh));
+        const int ro_ = DMA ? dual_off(32 * g + r, 2 * s + hh) : row_off(32 * g + r, 2 * s + hh);
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qr(buf) + ro_);
+        const bf16x8 oa = *reinterpret_cast<const bf16x8*>(Or(buf) + ro_);
         sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], sm, 0, 0, 0);
         dpm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[s], dpm, 0, 0, 0);
       }
@@ -487,8 +519,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const unsigned short* _
         const bf16x8 pf = cvt8(sm, 8 * s), dsf = cvt8(ds, 8 * s);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-          dvt[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot(buf), 32 * g + 16 * s, n, lane), pf, dvt[n], 0, 0, 0);
-          dkt[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt(buf), 32 * g + 16 * s, n, lane), dsf, dkt[n], 0, 0, 0);
+          dvt[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(DMA ? tr_frag_dual(Ot(buf), 32 * g + 16 * s, n, lane) : tr_frag(Ot(buf), 32 * g + 16 * s, n, lane), pf, dvt[n], 0, 0, 0);
+          dkt[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(DMA ? tr_frag_dual(Qt(buf), 32 * g + 16 * s, n, lane) : tr_frag(Qt(buf), 32 * g + 16 * s, n, lane), dsf, dkt[n], 0, 0, 0);
         }
       }
     }
