@@ -22,6 +22,12 @@
 //   * the zero rows 0 and T + 1 of every segment (Conv1d padding of conv2) are written by the first / last chunk.
 #include "common.h"
 
+#ifndef GWW_C1M_TABLE
+#define GWW_C1M_TABLE 0   // 1 (round 4 experiment): GELU through a 1 024-interval Phi table in LDS -- more exact (7.4e-6) and 5 % SLOWER
+                          // (0.276 against 0.262 ms per 256 segments): 96 random 8-byte LDS reads per lane and chunk cost more than the
+                          // 192 quarter-rate transcendentals they replace
+#endif
+
 namespace gww {
 
 namespace {
@@ -39,6 +45,25 @@ __global__ __launch_bounds__(512, 1) void k_conv1_mel(const float* __restrict__ 
                                                       const float* __restrict__ bias, unsigned short* __restrict__ c1,
                                                       int T, int d, int chunks_per_seg, int n_items) {
   __shared__ __attribute__((aligned(16))) unsigned char tile[2 * C1M_BUF];
+#if GWW_C1M_TABLE
+  // GELU by table: Phi on [-8, 8) in 1 024 intervals with its forward difference beside it -- gelu(x) = x (Phi_i + f dPhi_i),
+  // linear interpolation error <= h^2 / 8 max |Phi''| = 7.4e-6 (the sigmoid-quintic form: 2.6e-5).  Seven plain VALU operations
+  // and one 8-byte LDS read per value instead of seven + v_exp_f32 + v_rcp_f32 (quarter rate): the epilogue is what bounds
+  // this kernel.  8 KB, filled once per (persistent) workgroup.
+  __shared__ __attribute__((aligned(16))) float2 phi_tab[1024];
+  for (int i = threadIdx.x; i < 1024; i += 512) {
+    const float x0 = -8.0f + i * (1.0f / 64.0f), x1 = x0 + (1.0f / 64.0f);
+    const float p0 = 0.5f * (1.0f + erff(x0 * 0.70710678118654752440f)), p1 = 0.5f * (1.0f + erff(x1 * 0.70710678118654752440f));
+    phi_tab[i] = make_float2(p0, p1 - p0);
+  }
+  auto gelu_tab = [&](float x) -> float {
+    float t = fmaf(x, 64.0f, 512.0f);
+    t = __builtin_amdgcn_fmed3f(t, 0.0f, 1023.9999f);
+    const unsigned i = (unsigned)t;                 // (truncation: t >= 0)
+    const float2 pd = phi_tab[i];
+    return x * fmaf(__builtin_amdgcn_fractf(t), pd.y, pd.x);
+  };
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
   const int chb = (int)blockIdx.y * (128 * NCB) + wave * 16 * NCB;   // first channel of this wave
@@ -134,7 +159,11 @@ __global__ __launch_bounds__(512, 1) void k_conv1_mel(const float* __restrict__ 
         for (int cb = 0; cb < NCB; ++cb) {
           const f32x4 v = acc[cb] + bv[cb];
           // (x sigma(quintic): the epilogue is VALU-bound -- 96 values per lane per chunk against 3 072 cycles of MFMAs)
+#if GWW_C1M_TABLE
+          const u32x2 o = {pack2bf(gelu_tab(v[0]), gelu_tab(v[1])), pack2bf(gelu_tab(v[2]), gelu_tab(v[3]))};
+#else
           const u32x2 o = {pack2bf(gelu_sig4(v[0]), gelu_sig4(v[1])), pack2bf(gelu_sig4(v[2]), gelu_sig4(v[3]))};
+#endif
           *reinterpret_cast<u32x2*>(out + (long)tok * d + 16 * cb) = o;
         }
       }
